@@ -1,0 +1,202 @@
+/*
+ * softray.h -- C ABI of libsoftray_hip.so: the MI355X (gfx950) implementation of Engine3D's
+ * per-pixel raytrace hot path (voidstar69/softray: Engine3D/Raytrace/ + the raytrace half of
+ * Engine3D/Renderer.cs).
+ *
+ * The reference has NO native/FFI boundary (pure C#, single process).  The seam is cut
+ * where the reference fans out to worker tasks:
+ *
+ *     Renderer.RaytraceBlock(instance, geometry, left, top, sizeX, sizeY)      Engine3D/Renderer.cs:1690
+ *
+ * Everything RaytraceBlock and the decorators below it read is passed in `sr_frame`; everything
+ * PreCalculate() builds once per model is held in `sr_scene`.  A C# `[DllImport("softray_hip")]`
+ * shim inside a Renderer-compatible class binds exactly these entry points
+ * (bindings/csharp/GpuRenderer.cs); so do the ctypes mirror (softray_amd/) and the
+ * C++ mirror (softray_amd/host/).
+ *
+ * Conventions: plain pointers and sizes only; every call is blocking unless it takes a stream; all
+ * input arrays are copied; the library never retains a caller pointer after returning; a scene is
+ * single-threaded like the reference ("Must only be executed by a single thread at a time",
+ * Renderer.cs:1498), distinct scenes are independent.  Return value 0 = ok, <0 = SR_ERR_*;
+ * sr_last_error() gives the thread-local message the shim wraps into the matching .NET exception.
+ * There is NO CPU fallback: without a usable HIP device every compute call fails with
+ * SR_ERR_NO_DEVICE.
+ */
+#ifndef SOFTRAY_H
+#define SOFTRAY_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SR_ABI_VERSION 1
+
+enum {
+    SR_OK                 =  0,
+    SR_ERR_INVALID_ARG    = -1,   /* ArgumentException / ArgumentNullException                         */
+    SR_ERR_OUT_OF_RANGE   = -2,   /* ArgumentOutOfRangeException: "A triangle vertex is outside the
+                                     bounding box" (SpatialSubdivision.cs:287-295)                      */
+    SR_ERR_NO_MODEL       = -3,   /* no triangles set: Renderer.Render() returns silently
+                                     (Renderer.cs:736-739); the shim does the same                      */
+    SR_ERR_NOT_BUILT      = -4,   /* sr_build() not called for the requested trace mode                */
+    SR_ERR_UNSUPPORTED    = -5,
+    SR_ERR_NO_DEVICE      = -6,   /* no HIP device / host-only scene: compute is refused, never emulated */
+    SR_ERR_HIP            = -7,   /* a HIP runtime call failed (message in sr_last_error)               */
+    SR_ERR_FORMAT         = -8    /* FormatException (3DS loader, ThreeDSFile.cs:166-169, Model.cs:553) */
+};
+
+/* per-frame flags = the public bool fields of Renderer (Renderer.cs:56-57,76-77,84) */
+enum {
+    SR_F_SHADING     = 1u << 0,   /* rayTraceShading  -> ShadingMethod.Enabled  (Renderer.cs:1614)      */
+    SR_F_SHADOWS     = 1u << 1,   /* rayTraceShadows (dynamic) -> ShadowMethod.Enabled (:1632)          */
+    SR_F_FOCAL_BLUR  = 1u << 2,   /* rayTraceFocalBlur (only read when sub_pixel_res > 1, :1744-1790)   */
+    SR_F_POINT_LIGHT = 1u << 3,   /* pointLighting   (Scene.cs:20)                                      */
+    SR_F_SPECULAR    = 1u << 4    /* specularLighting (Scene.cs:21)                                     */
+};
+
+/* how the model's triangles are intersected */
+enum {
+    SR_MODE_REF_TREE = 0,  /* SpatialSubdivision.IntersectRay, literal (rayTraceSubdivision = true);
+                              same tree, same near/far order, same leaf-box containment rule            */
+    SR_MODE_BRUTE    = 1,  /* GeometryCollection over geometry_simple (rayTraceSubdivision = false)     */
+    SR_MODE_BVH      = 2   /* the library's own BVH: global nearest hit with the reference's per-triangle
+                              arithmetic (same root-box clip, same rayFrac offset, hit must lie inside the
+                              root box, ties -> lowest triangle index).  Identical to REF_TREE except for
+                              hits closer than 1e-10 to a leaf-box face of the reference tree            */
+};
+
+/* ExtraGeometryToRaytrace element (Renderer.cs:460,1545-1549).  Order is preserved: the collection is
+ * scanned first-to-last with a strict '<' on rayFrac (GeometryCollection.cs:44-69), then the model. */
+typedef struct {
+    int32_t  kind;      /* 0 Sphere {centre xyz, radius}          Raytrace/Sphere.cs:26-33
+                           1 Plane  {point xyz, normal xyz}       Raytrace/Plane.cs:22-29
+                           2 Triangle {v1, v2, v3}                Raytrace/Triangle.cs:29-57            */
+    uint32_t argb;      /* Color.ToARGB() of the primitive's Color                                      */
+    double   p[9];
+} sr_prim;
+
+/* Everything RaytraceGeometry / RaytraceBlock / ShadingMethod / ShadowMethod read per frame
+ * (Renderer.cs:1501-1829).  The host side (C# shim, C++ or ctypes mirror) fills it from the public
+ * Renderer / Instance fields; the matrices are Instance.InitRender's (Instance.cs:134-135) so that the
+ * host's own sin/cos are the ones used.  sr_instance_matrices() builds them for hosts that want it. */
+typedef struct {
+    int32_t  width, height;          /* SetRenderingSurface (Renderer.cs:593)                            */
+    int32_t  start_row, end_row;     /* rayTraceStartRow / rayTraceEndRow, inclusive (:135-136,1652-1653)
+                                        rendered EXACTLY (the reference's last task may overshoot by up to
+                                        rayTraceConcurrency-1 rows, :1659-1670; those rows are identical) */
+    int32_t  sub_pixel_res;          /* rayTraceSubPixelRes (:90)                                        */
+    uint32_t background_argb;        /* BackgroundColor (:308); misses store it with alpha 0xFF (:1860)  */
+    uint32_t flags;                  /* SR_F_*                                                           */
+    int32_t  random_seed;            /* rayTraceRandomSeed (:92): area-light offsets, ShadowMethod.cs:63 */
+    int32_t  shadow_samples;         /* 0 => 100 = softShadowQuality (ShadowMethod.cs:9). 1 with a zero
+                                        offset table = hard-shadow variant (build-defined, unpinned)      */
+    int32_t  trace_mode;             /* SR_MODE_*                                                        */
+    int32_t  strip_rows, strip_count, strip_index;
+                                     /* multi-GPU row interleave: this call renders rows r in
+                                        [start_row,end_row] with (r / strip_rows) % strip_count ==
+                                        strip_index into a COMPACT buffer (owned rows in order).
+                                        strip_count == 0: off, pixels is the full W*H surface            */
+    int32_t  max_bounces;            /* reserved (config-5 mirror-reflection extension); must be 0       */
+    double   transform[12];          /* rows 0..2 of Instance._transform        (Instance.cs:134)        */
+    double   inv_transform[12];      /* rows 0..2 of Instance._inverseTransform (Instance.cs:135)        */
+    double   position_z;             /* Instance.Position.z (:1717, Instance.cs:182)                     */
+    double   fov_depth;              /* Renderer.fieldOfViewDepth = 0.5 / tan(pi/8) (:101)               */
+    double   focal_depth;            /* rayTraceFocalDepth (:87)                                         */
+    double   focal_blur_strength;    /* rayTraceFocalBlurStrength (:88)                                  */
+    double   ambient, shininess;     /* ambientLight_intensity, specularLight_shininess (:38,:41)        */
+    double   light_dir_view[3];      /* directionalLight_dir (:39)                                       */
+    double   light_pos_view[3];      /* positionalLight_pos (:40)                                        */
+    double   reflectivity;           /* reserved; must be 0                                              */
+    const double* area_light_offsets;/* optional [shadow_samples][3] (e.g. produced by the C# shim with the
+                                        real System.Random); NULL => derived from random_seed             */
+} sr_frame;
+
+typedef struct sr_scene sr_scene;    /* one per Renderer; freed by Dispose() (Renderer.cs:236)           */
+
+/* device >= 0: HIP device ordinal.  device == -1: host-only scene (sr_set_*, sr_build, sr_tree_stats,
+ * sr_load_3ds work; every compute call returns SR_ERR_NO_DEVICE). */
+int  sr_create(int32_t device, sr_scene** out);
+void sr_destroy(sr_scene*);
+
+/* MakeRayTracableGeometry_simple (Renderer.cs:1452-1469): v9 = [n][3 vertices][xyz] in model space
+ * (after Model.PostProcessGeometry), argb[n] = Surface.PackColorAndAlpha(diffuse, 1.0) (:1463),
+ * box = AxisAlignedBox(model.Min, model.Max) (:1487).  TriangleIndex = position in the array (:1465). */
+int  sr_set_triangles(sr_scene*, const double* v9, const uint32_t* argb, int64_t n,
+                      const double box_min[3], const double box_max[3]);
+/* ExtraGeometryToRaytrace (Renderer.cs:460); n == 0 clears */
+int  sr_set_extra_geometry(sr_scene*, const sr_prim* prims, int32_t n);
+
+/* PreCalculate() (Renderer.cs:673-699).  modes = bit mask (1 << SR_MODE_*) of the structures to build:
+ * REF_TREE: new SpatialSubdivision(geom, box, max_depth, max_per_leaf) (SpatialSubdivision.cs:267-315;
+ * <=0 => the defaults 15 / 25, :269-270; SR_ERR_OUT_OF_RANGE if a vertex is outside the box);
+ * BVH: the library's own BVH; BRUTE needs nothing.  Host work + H2D copies. */
+int  sr_build(sr_scene*, uint32_t modes, int32_t max_depth, int32_t max_per_leaf);
+/* out = TreeDepth, NumNodes, NumLeafNodes, NumInternalNodes (SpatialSubdivision.cs:317-335) */
+int  sr_tree_stats(const sr_scene*, int32_t out[4]);
+
+/* Renderer.Render() for one Instance, raytrace path (Renderer.cs:701-778 -> RaytraceGeometry :1501 ->
+ * RaytraceBlock :1690).  pixels = caller-owned int[W*H] ARGB, row-major pixels[row*W+col]
+ * (Surface.DrawPixel, Surface.cs:174-181); only rows start_row..end_row are written; with strips the
+ * buffer is the compact strip buffer.  stats (may be NULL) = NumRaysFired, NumGeometryTests,
+ * NumNodeVisits, NumLeafNodeVisits (Renderer.cs:465-504) summed over the frame's PRIMARY rays
+ * (deterministic, unlike the reference's racy per-block counters, :1695). */
+int  sr_render(sr_scene*, const sr_frame*, int32_t* pixels, uint64_t stats[4]);
+/* Same, but `d_pixels` is DEVICE memory on the scene's device (e.g. a torch tensor's data_ptr) and the
+ * work is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream) without host sync. */
+int  sr_render_device(sr_scene*, const sr_frame*, void* d_pixels, void* hip_stream, uint64_t* d_stats /* device uint64[8] (see sr_last_ray_stats) or NULL */);
+/* number of int32 pixels sr_render writes for this frame (W*H, or the compact strip size) */
+int64_t sr_frame_pixel_count(const sr_frame*);
+
+/* IRayIntersectable.IntersectRay in batch (Raytrace/IRayIntersectable.cs:31-48): the operator interface
+ * every primitive, the tree and the decorators implement.  target = SR_MODE_* for the model alone, or
+ * SR_TARGET_ROOT = the root geometry of the chain (extra geometry + model in `mode`, Renderer.cs:1536-1549).
+ * Host arrays; outputs may be NULL.  counters[n][3] = NumRayTests, NumNodesVisited, NumLeafNodesVisited. */
+#define SR_TARGET_ROOT 0x100
+int  sr_trace_rays(sr_scene*, int32_t target, int64_t n, const double* starts, const double* dirs,
+                   uint8_t* hit, double* ray_frac, double* pos, double* normal, uint32_t* color,
+                   int32_t* tri_index, int32_t* counters);
+
+/* Instance.InitRender matrices (Instance.cs:134-135, Matrix.cs:74-169): T = Trans(P)*Roll*Pitch*Yaw,
+ * T^-1 = Yaw(-)*Pitch(-)*Roll(-)*Trans(-P); rows 0..2, row-major 3x4. */
+void sr_instance_matrices(const double position[3], double yaw, double pitch, double roll,
+                          double transform[12], double inv_transform[12]);
+/* Renderer.fieldOfViewDepth (Renderer.cs:97-101) */
+double sr_default_fov_depth(void);
+/* ShadowMethod ctor (ShadowMethod.cs:63-73) with new Random(seed) (Renderer.cs:1624): out[count][3] */
+void sr_area_light_offsets(int32_t seed, int32_t count, double* out3);
+
+/* Model.Load3ds + Model.PostProcessGeometry (Model.cs:522-653,750-831; 3dsLoader/ThreeDSFile.cs:132-662):
+ * parses a .3DS image and fills the scene's triangles / colours / box (= sr_set_triangles).  The counts
+ * and the arrays can be read back with sr_get_triangles. */
+int  sr_load_3ds(sr_scene*, const uint8_t* data, size_t len);
+int64_t sr_num_triangles(const sr_scene*);
+int  sr_get_triangles(const sr_scene*, double* v9, uint32_t* argb, double box_min[3], double box_max[3]);
+
+/* timing of the kernels launched by the last sr_render / sr_render_device (HIP events on the launch
+ * stream).  names[i] points to a static string.  Returns the number of entries written (<= cap). */
+typedef struct { const char* name; float ms; int32_t launches; } sr_kernel_time;
+int  sr_last_kernel_times(sr_scene*, sr_kernel_time* out, int32_t cap);
+
+/* Ray statistics of the last sr_render(..., stats != NULL): primary {rays, triangle/primitive tests, nodes
+ * visited, leaf nodes visited} followed by the same four for secondary (shadow) rays.  These are the
+ * counters the roofline's algorithmic bytes are priced from (DESIGN.md "Measurement"). */
+int  sr_last_ray_stats(const sr_scene*, uint64_t out[8]);
+
+/* Seeded synthetic triangle soup = SpatialSubdivisionTests.MakeRandomTriangles
+ * (Engine3D-Tests/Raytrace/SpatialSubdivisionTests.cs:397-411) driven by the System.Random port: per triangle
+ * v1 = U[0,space)^3 + origin, v2 = v1 + U[0,extent)^3, v3 = v1 + U[0,extent)^3, colour = (uint)Next()
+ * (opaque != 0: 0xFF000000 | low 24 bits).  Used by bench.py and the tests so that C#, the CPU checker and
+ * the device regenerate identical inputs. */
+void sr_make_random_triangles(int32_t seed, int64_t n, double space, double extent, double origin, int32_t opaque,
+                              double* v9, uint32_t* argb);
+
+const char* sr_last_error(void);
+int32_t     sr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

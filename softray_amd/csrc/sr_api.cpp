@@ -1,0 +1,487 @@
+// sr_api.cpp -- the C ABI of libsoftray_hip.so (include/softray.h): scene ownership, H2D staging,
+// per-frame constant preparation and kernel dispatch.  There is no CPU compute path in here: a scene
+// without a HIP device refuses every compute call with SR_ERR_NO_DEVICE.
+// Compile with -ffp-contract=off (the per-frame constants must round like the reference's C#).
+#include "../../include/softray.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sr_device.h"
+#include "sr_host.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    g_err = std::string(what) + ": " + hipGetErrorString(e);
+    return SR_ERR_HIP;
+}
+#define SR_HIP(call)                                         \
+    do {                                                     \
+        hipError_t e__ = (call);                             \
+        if (e__ != hipSuccess) return hip_fail(e__, #call);  \
+    } while (0)
+
+// growable device buffer
+struct DBuf {
+    void*  p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap && p) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+        size_t want = std::max<size_t>(bytes, 256);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    template <class T> hipError_t upload(const std::vector<T>& v) {
+        hipError_t e = reserve(v.size() * sizeof(T));
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct sr_scene {
+    int device = -1;
+    // host copies (what Renderer keeps between frames)
+    std::vector<double>   v9;
+    std::vector<uint32_t> argb;
+    double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+    bool have_model = false;
+    std::vector<sr::Rec128> tri_recs;      // geometry_simple, Renderer.cs:1452-1469
+    std::vector<sr::Rec128> extra_recs;    // ExtraGeometryToRaytrace
+    sr::RootBox root{};
+    sr::RefTree ref;
+    sr::Bvh     bvh;
+    // device state
+    DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris;
+    DBuf d_offsets, d_rowmap, d_pixels, d_stats, d_io[9];
+    bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
+    std::vector<double>  offsets_host;
+    std::vector<int32_t> rowmap_host;
+    // timing of the last render
+    hipEvent_t ev[sr::K_COUNT][2] = {};
+    bool ev_made = false;
+    int  ev_launches[sr::K_COUNT] = {};
+    uint64_t last_stats[8] = {};
+};
+
+namespace {
+
+int use_device(sr_scene* s) {
+    if (s->device < 0) return fail(SR_ERR_NO_DEVICE, "host-only scene: no HIP device bound (compute is never emulated on the CPU)");
+    SR_HIP(hipSetDevice(s->device));
+    return SR_OK;
+}
+
+int sync_geometry(sr_scene* s, uint32_t need_mode) {
+    if (s->tris_dirty) { SR_HIP(s->d_tris.upload(s->tri_recs)); s->tris_dirty = false; }
+    if (s->extra_dirty) { SR_HIP(s->d_extra.upload(s->extra_recs)); s->extra_dirty = false; }
+    if (need_mode == SR_MODE_REF_TREE && s->ref_dirty) {
+        SR_HIP(s->d_rnodes.upload(s->ref.nodes));
+        SR_HIP(s->d_rboxes.upload(s->ref.leaf_boxes));
+        SR_HIP(s->d_rleaf.upload(s->ref.leaf_tris));
+        s->ref_dirty = false;
+    }
+    if (need_mode == SR_MODE_BVH && s->bvh_dirty) {
+        SR_HIP(s->d_bnodes.upload(s->bvh.nodes));
+        std::vector<sr::Rec128> ordered(s->bvh.order.size());
+        for (size_t i = 0; i < ordered.size(); ++i) ordered[i] = s->tri_recs[s->bvh.order[i]];
+        SR_HIP(s->d_btris.upload(ordered));
+        s->bvh_dirty = false;
+    }
+    return SR_OK;
+}
+
+sr::DevScene dev_scene(const sr_scene* s) {
+    sr::DevScene d{};
+    d.tris = (const sr::Rec128*)s->d_tris.p; d.ntris = (int32_t)s->tri_recs.size();
+    d.extra = (const sr::Rec128*)s->d_extra.p; d.nextra = (int32_t)s->extra_recs.size();
+    d.rnodes = (const sr::RefNode*)s->d_rnodes.p; d.rboxes = (const sr::LeafBox*)s->d_rboxes.p; d.rleaf = (const int32_t*)s->d_rleaf.p;
+    d.rdepth = s->ref.tree_depth;
+    d.bnodes = (const sr::BvhNode*)s->d_bnodes.p; d.btris = (const sr::Rec128*)s->d_btris.p; d.bdepth = s->bvh.depth;
+    d.root = s->root;
+    return d;
+}
+
+int check_mode(const sr_scene* s, int mode) {
+    if (!s->have_model || s->tri_recs.empty()) return fail(SR_ERR_NO_MODEL, "no model: Render() returns without drawing (Renderer.cs:736-739)");
+    if (mode == SR_MODE_REF_TREE && !s->ref.built) return fail(SR_ERR_NOT_BUILT, "SR_MODE_REF_TREE needs sr_build(1 << SR_MODE_REF_TREE)");
+    if (mode == SR_MODE_REF_TREE && s->ref.tree_depth > 120) return fail(SR_ERR_UNSUPPORTED, "reference tree deeper than 120 levels does not fit the LDS traversal stacks");
+    if (mode == SR_MODE_BVH && !s->bvh.built) return fail(SR_ERR_NOT_BUILT, "SR_MODE_BVH needs sr_build(1 << SR_MODE_BVH)");
+    if (mode != SR_MODE_REF_TREE && mode != SR_MODE_BRUTE && mode != SR_MODE_BVH) return fail(SR_ERR_INVALID_ARG, "unknown trace mode");
+    return SR_OK;
+}
+
+bool row_owned(const sr_frame* f, int r) {
+    if (f->strip_count <= 0) return true;
+    return ((r / f->strip_rows) % f->strip_count) == f->strip_index;
+}
+
+int validate_frame(const sr_frame* f) {
+    if (!f) return fail(SR_ERR_INVALID_ARG, "frame is NULL");
+    if (f->width <= 0 || f->height <= 0) return fail(SR_ERR_INVALID_ARG, "surface size must be positive");
+    if (f->sub_pixel_res < 1 || f->sub_pixel_res > 64) return fail(SR_ERR_INVALID_ARG, "sub_pixel_res out of range");
+    if (f->strip_count < 0 || (f->strip_count > 0 && (f->strip_rows <= 0 || f->strip_index < 0 || f->strip_index >= f->strip_count)))
+        return fail(SR_ERR_INVALID_ARG, "bad strip parameters");
+    if (f->shadow_samples < 0 || f->shadow_samples > 4096) return fail(SR_ERR_INVALID_ARG, "shadow_samples out of range");
+    if (f->max_bounces != 0 || f->reflectivity != 0.0) return fail(SR_ERR_UNSUPPORTED, "reflection extension is not implemented");
+    return SR_OK;
+}
+
+void clamp_rows(const sr_frame* f, int& a, int& b) {                  // Renderer.cs:1652-1653
+    a = std::min(std::max(0, f->start_row), f->height - 1);
+    b = std::min(std::max(0, f->end_row), f->height - 1);
+}
+
+// everything RaytraceGeometry derives per frame (Renderer.cs:1510-1528, 1717)
+int prepare_frame(sr_scene* s, const sr_frame* f, sr::FrameConst& fc) {
+    std::memset(&fc, 0, sizeof(fc));
+    fc.width = f->width; fc.height = f->height;
+    fc.sub_pixel_res = f->sub_pixel_res;
+    fc.background = f->background_argb | 0xFF000000u;               // BackgroundColorWithAlpha, :325-331
+    fc.flags = f->flags;
+    fc.shadow_samples = f->shadow_samples > 0 ? f->shadow_samples : 100;   // ShadowMethod.cs:9
+    fc.strip_rows = f->strip_rows; fc.strip_count = f->strip_count; fc.strip_index = f->strip_index;
+    int a, b;
+    clamp_rows(f, a, b);
+    fc.start_row = a;
+    s->rowmap_host.clear();
+    for (int r = a; r <= b; ++r) if (row_owned(f, r)) s->rowmap_host.push_back(r);
+    fc.num_rows = (int32_t)s->rowmap_host.size();
+    fc.first_row = fc.num_rows ? s->rowmap_host[0] : 0;
+    for (int i = 0; i < 12; ++i) { fc.t[i] = f->transform[i]; fc.it[i] = f->inv_transform[i]; }
+    fc.position_z = f->position_z; fc.fov_depth = f->fov_depth;
+    fc.focal_depth = f->focal_depth; fc.focal_blur_strength = f->focal_blur_strength;
+    fc.ambient = f->ambient; fc.shininess = f->shininess;
+    const double* it = fc.it;
+    for (int i = 0; i < 3; ++i) { fc.light_dir_view[i] = f->light_dir_view[i]; fc.light_pos_view[i] = f->light_pos_view[i]; }
+    const double* ld = f->light_dir_view; const double* lp = f->light_pos_view;
+    for (int r = 0; r < 3; ++r) {
+        // Instance.TransformDirectionReverse (Instance.cs:229-235) and TransformPosFromView (:192-209, which
+        // IGNORES its un-projection and returns inverseTransform(3x4) * pos -- kept)
+        fc.light_dir_model[r] = ld[0] * it[4 * r] + ld[1] * it[4 * r + 1] + ld[2] * it[4 * r + 2];
+        fc.light_pos_model[r] = lp[0] * it[4 * r] + lp[1] * it[4 * r + 1] + lp[2] * it[4 * r + 2] + it[4 * r + 3];
+        const double vx = 0.0, vy = 0.0, vz = -f->position_z;         // new Vector(0, 0, -instance.Position.z), :1717
+        fc.start_world[r] = vx * it[4 * r] + vy * it[4 * r + 1] + vz * it[4 * r + 2];
+    }
+    fc.aspect = (double)f->height / (double)f->width;               // Renderer.cs:621
+
+    // area-light offsets (ShadowMethod.cs:63-73)
+    s->offsets_host.resize((size_t)fc.shadow_samples * 3);
+    if (f->area_light_offsets) std::memcpy(s->offsets_host.data(), f->area_light_offsets, s->offsets_host.size() * sizeof(double));
+    else sr::area_light_offsets(f->random_seed, fc.shadow_samples, s->offsets_host.data());
+    return SR_OK;
+}
+
+int ensure_events(sr_scene* s) {
+    if (s->ev_made) return SR_OK;
+    for (int k = 0; k < sr::K_COUNT; ++k)
+        for (int j = 0; j < 2; ++j) SR_HIP(hipEventCreate(&s->ev[k][j]));
+    s->ev_made = true;
+    return SR_OK;
+}
+
+int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_t stream, unsigned long long* d_stats) {
+    sr::FrameConst fc;
+    int rc = prepare_frame(s, f, fc);
+    if (rc) return rc;
+    if ((rc = sync_geometry(s, (uint32_t)f->trace_mode))) return rc;
+    if ((rc = ensure_events(s))) return rc;
+    SR_HIP(s->d_offsets.reserve(s->offsets_host.size() * sizeof(double)));
+    SR_HIP(hipMemcpyAsync(s->d_offsets.p, s->offsets_host.data(), s->offsets_host.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    SR_HIP(s->d_rowmap.reserve(std::max<size_t>(1, s->rowmap_host.size()) * sizeof(int32_t)));
+    if (!s->rowmap_host.empty())
+        SR_HIP(hipMemcpyAsync(s->d_rowmap.p, s->rowmap_host.data(), s->rowmap_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+    for (int k = 0; k < sr::K_COUNT; ++k) s->ev_launches[k] = 0;
+
+    sr::RenderLaunch L{};
+    L.sc = dev_scene(s);
+    L.fc = fc;
+    L.mode = f->trace_mode;
+    L.offsets = (const double*)s->d_offsets.p;
+    L.row_map = (const int32_t*)s->d_rowmap.p;
+    L.pixels = d_pixels;
+    L.stats = d_stats;
+    L.stream = stream;
+    SR_HIP(hipEventRecord(s->ev[sr::K_RENDER][0], stream));
+    SR_HIP(sr::launch_render(L));
+    SR_HIP(hipEventRecord(s->ev[sr::K_RENDER][1], stream));
+    s->ev_launches[sr::K_RENDER] = 1;
+    return SR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t sr_abi_version(void) { return SR_ABI_VERSION; }
+const char* sr_last_error(void) { return g_err.c_str(); }
+
+int sr_create(int32_t device, sr_scene** out) {
+    if (!out) return fail(SR_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (device >= 0) {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0) return fail(SR_ERR_NO_DEVICE, "no HIP device available (libsoftray_hip has no CPU fallback)");
+        if (device >= count) return fail(SR_ERR_INVALID_ARG, "device ordinal out of range");
+        SR_HIP(hipSetDevice(device));
+    } else if (device != -1) {
+        return fail(SR_ERR_INVALID_ARG, "device must be >= 0, or -1 for a host-only scene");
+    }
+    sr_scene* s = new sr_scene();
+    s->device = device;
+    *out = s;
+    return SR_OK;
+}
+
+void sr_destroy(sr_scene* s) {
+    if (!s) return;
+    if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
+        DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris,
+                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_stats};
+        for (DBuf* b : bufs) b->release();
+        for (DBuf& b : s->d_io) b.release();
+        if (s->ev_made)
+            for (int k = 0; k < sr::K_COUNT; ++k)
+                for (int j = 0; j < 2; ++j) (void)hipEventDestroy(s->ev[k][j]);
+    }
+    delete s;
+}
+
+int sr_set_triangles(sr_scene* s, const double* v9, const uint32_t* argb, int64_t n, const double box_min[3], const double box_max[3]) {
+    if (!s || n < 0 || (n > 0 && (!v9 || !argb)) || !box_min || !box_max) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_set_triangles");
+    if (n > 0x7fffff00) return fail(SR_ERR_INVALID_ARG, "too many triangles");
+    s->v9.assign(v9, v9 + 9 * n);
+    s->argb.assign(argb, argb + n);
+    for (int a = 0; a < 3; ++a) { s->bmin[a] = box_min[a]; s->bmax[a] = box_max[a]; }
+    s->root = sr::make_root_box(box_min, box_max);
+    s->tri_recs.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) {
+        const double* p = &s->v9[9 * i];
+        s->tri_recs[i] = sr::make_triangle_record({p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}, argb[i], (int32_t)i);
+    }
+    s->have_model = true;
+    s->ref = sr::RefTree();
+    s->bvh = sr::Bvh();
+    s->tris_dirty = s->ref_dirty = s->bvh_dirty = true;
+    return SR_OK;
+}
+
+int sr_set_extra_geometry(sr_scene* s, const sr_prim* prims, int32_t n) {
+    if (!s || n < 0 || (n > 0 && !prims)) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_set_extra_geometry");
+    std::vector<sr::Rec128> recs;
+    for (int i = 0; i < n; ++i) {
+        const sr_prim& q = prims[i];
+        switch (q.kind) {
+            case 0:
+                if (!(q.p[3] > 0)) return fail(SR_ERR_INVALID_ARG, "sphere radius must be > 0 (Sphere.cs:28)");
+                recs.push_back(sr::make_sphere_record({q.p[0], q.p[1], q.p[2]}, q.p[3], q.argb));
+                break;
+            case 1: recs.push_back(sr::make_plane_record({q.p[0], q.p[1], q.p[2]}, {q.p[3], q.p[4], q.p[5]}, q.argb)); break;
+            case 2: {
+                sr::Rec128 r = sr::make_triangle_record({q.p[0], q.p[1], q.p[2]}, {q.p[3], q.p[4], q.p[5]}, {q.p[6], q.p[7], q.p[8]}, q.argb, 2);
+                recs.push_back(r);
+                break;
+            }
+            default: return fail(SR_ERR_INVALID_ARG, "unknown primitive kind");
+        }
+    }
+    s->extra_recs.swap(recs);
+    s->extra_dirty = true;
+    return SR_OK;
+}
+
+int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_leaf) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "scene is NULL");
+    if (!s->have_model) return fail(SR_ERR_NO_MODEL, "sr_build before sr_set_triangles");
+    if (modes & (1u << SR_MODE_REF_TREE)) {
+        int md = max_depth > 0 ? max_depth : 15, mg = max_per_leaf > 0 ? max_per_leaf : 25;   // SpatialSubdivision.cs:269-270
+        if (!sr::build_ref_tree(s->v9, s->bmin, s->bmax, md, mg, s->ref))
+            return fail(SR_ERR_OUT_OF_RANGE, "A triangle vertex is outside the bounding box");
+        s->ref_dirty = true;
+    }
+    if (modes & (1u << SR_MODE_BVH)) {
+        sr::build_bvh(s->v9, s->root, s->bvh);
+        if (s->bvh.depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
+        s->bvh_dirty = true;
+    }
+    if (s->device >= 0) {
+        int rc = use_device(s);
+        if (rc) return rc;
+        if (modes & (1u << SR_MODE_REF_TREE)) if ((rc = sync_geometry(s, SR_MODE_REF_TREE))) return rc;
+        if (modes & (1u << SR_MODE_BVH)) if ((rc = sync_geometry(s, SR_MODE_BVH))) return rc;
+        if ((rc = sync_geometry(s, SR_MODE_BRUTE))) return rc;
+    }
+    return SR_OK;
+}
+
+int sr_tree_stats(const sr_scene* s, int32_t out[4]) {
+    if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
+    if (!s->ref.built) return fail(SR_ERR_NOT_BUILT, "reference tree not built");
+    out[0] = s->ref.tree_depth; out[1] = s->ref.num_nodes; out[2] = s->ref.num_leaf_nodes; out[3] = s->ref.num_nodes - s->ref.num_leaf_nodes;
+    return SR_OK;
+}
+
+int64_t sr_frame_pixel_count(const sr_frame* f) {
+    if (!f || f->width <= 0 || f->height <= 0) return 0;
+    if (f->strip_count <= 0) return (int64_t)f->width * f->height;
+    int a, b;
+    clamp_rows(f, a, b);
+    int64_t rows = 0;
+    for (int r = a; r <= b; ++r) if (row_owned(f, r)) rows++;
+    return rows * f->width;
+}
+
+int sr_render_device(sr_scene* s, const sr_frame* f, void* d_pixels, void* hip_stream, uint64_t* d_stats) {
+    if (!s || !d_pixels) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_render_device");
+    int rc = validate_frame(f);
+    if (rc) return rc;
+    if ((rc = check_mode(s, f->trace_mode))) return rc;
+    if ((rc = use_device(s))) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (d_stats) SR_HIP(hipMemsetAsync(d_stats, 0, 8 * sizeof(uint64_t), stream));
+    return render_common(s, f, (uint32_t*)d_pixels, stream, (unsigned long long*)d_stats);
+}
+
+int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]) {
+    if (!s || !pixels) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_render");
+    int rc = validate_frame(f);
+    if (rc) return rc;
+    if ((rc = check_mode(s, f->trace_mode))) return rc;
+    if ((rc = use_device(s))) return rc;
+    int64_t count = sr_frame_pixel_count(f);
+    SR_HIP(s->d_pixels.reserve((size_t)count * 4));
+    unsigned long long* d_stats = nullptr;
+    if (stats) {
+        SR_HIP(s->d_stats.reserve(8 * sizeof(uint64_t)));
+        SR_HIP(hipMemsetAsync(s->d_stats.p, 0, 8 * sizeof(uint64_t), nullptr));
+        d_stats = (unsigned long long*)s->d_stats.p;
+    }
+    if ((rc = render_common(s, f, (uint32_t*)s->d_pixels.p, nullptr, d_stats))) return rc;
+    SR_HIP(hipStreamSynchronize(nullptr));
+    // only the rows the reference would have drawn are copied back into the caller's surface
+    if (f->strip_count > 0) {
+        if (count > 0) SR_HIP(hipMemcpy(pixels, s->d_pixels.p, (size_t)count * 4, hipMemcpyDeviceToHost));
+    } else {
+        int a, b;
+        clamp_rows(f, a, b);
+        size_t off = (size_t)a * f->width;
+        size_t n = (size_t)(b - a + 1) * f->width;
+        SR_HIP(hipMemcpy(pixels + off, (const int32_t*)s->d_pixels.p + off, n * 4, hipMemcpyDeviceToHost));
+    }
+    if (stats) {
+        SR_HIP(hipMemcpy(s->last_stats, s->d_stats.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        std::memcpy(stats, s->last_stats, 4 * sizeof(uint64_t));
+    }
+    return SR_OK;
+}
+
+int sr_trace_rays(sr_scene* s, int32_t target, int64_t n, const double* starts, const double* dirs, uint8_t* hit, double* ray_frac,
+                  double* pos, double* normal, uint32_t* color, int32_t* tri_index, int32_t* counters) {
+    if (!s || n < 0 || (n > 0 && (!starts || !dirs))) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_trace_rays");
+    bool with_extra = (target & SR_TARGET_ROOT) != 0;
+    int mode = target & 0xff;
+    if (!s->have_model) return fail(SR_ERR_NO_MODEL, "no model");
+    int rc;
+    if (s->tri_recs.empty() && mode == SR_MODE_BRUTE) { /* empty model is fine for brute force */ }
+    else if ((rc = check_mode(s, mode))) return rc;
+    if ((rc = use_device(s))) return rc;
+    if ((rc = sync_geometry(s, (uint32_t)mode))) return rc;
+    if (n == 0) return SR_OK;
+    size_t sizes[9] = {(size_t)n * 24, (size_t)n * 24, (size_t)n, (size_t)n * 8, (size_t)n * 24, (size_t)n * 24, (size_t)n * 4, (size_t)n * 4, (size_t)n * 12};
+    for (int i = 0; i < 9; ++i) SR_HIP(s->d_io[i].reserve(sizes[i]));
+    SR_HIP(hipMemcpy(s->d_io[0].p, starts, sizes[0], hipMemcpyHostToDevice));
+    SR_HIP(hipMemcpy(s->d_io[1].p, dirs, sizes[1], hipMemcpyHostToDevice));
+    sr::TraceLaunch L{};
+    L.sc = dev_scene(s);
+    L.mode = mode;
+    L.with_extra = with_extra && !s->extra_recs.empty();
+    L.n = n;
+    L.starts = (const double*)s->d_io[0].p; L.dirs = (const double*)s->d_io[1].p;
+    L.hit = (uint8_t*)s->d_io[2].p; L.ray_frac = (double*)s->d_io[3].p; L.pos = (double*)s->d_io[4].p; L.normal = (double*)s->d_io[5].p;
+    L.color = (uint32_t*)s->d_io[6].p; L.tri = (int32_t*)s->d_io[7].p; L.counters = (int32_t*)s->d_io[8].p;
+    L.stream = nullptr;
+    SR_HIP(sr::launch_trace(L));
+    SR_HIP(hipStreamSynchronize(nullptr));
+    void* outs[7] = {hit, ray_frac, pos, normal, color, tri_index, counters};
+    for (int i = 0; i < 7; ++i)
+        if (outs[i]) SR_HIP(hipMemcpy(outs[i], s->d_io[2 + i].p, sizes[2 + i], hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+void sr_instance_matrices(const double position[3], double yaw, double pitch, double roll, double transform[12], double inv_transform[12]) {
+    sr::instance_matrices(position, yaw, pitch, roll, transform, inv_transform);
+}
+double sr_default_fov_depth(void) { return sr::default_fov_depth(); }
+void sr_area_light_offsets(int32_t seed, int32_t count, double* out3) { sr::area_light_offsets(seed, count, out3); }
+
+int sr_load_3ds(sr_scene* s, const uint8_t* data, size_t len) {
+    if (!s || !data) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_load_3ds");
+    sr::LoadedModel m;
+    std::string err = sr::load_3ds(data, len, m);
+    if (!err.empty()) return fail(SR_ERR_FORMAT, err);
+    return sr_set_triangles(s, m.v9.data(), m.argb.data(), (int64_t)m.argb.size(), m.bmin, m.bmax);
+}
+int64_t sr_num_triangles(const sr_scene* s) { return s ? (int64_t)s->argb.size() : 0; }
+int sr_get_triangles(const sr_scene* s, double* v9, uint32_t* argb, double box_min[3], double box_max[3]) {
+    if (!s || !s->have_model) return fail(SR_ERR_NO_MODEL, "no model");
+    if (v9) std::memcpy(v9, s->v9.data(), s->v9.size() * sizeof(double));
+    if (argb) std::memcpy(argb, s->argb.data(), s->argb.size() * sizeof(uint32_t));
+    for (int a = 0; a < 3; ++a) { if (box_min) box_min[a] = s->bmin[a]; if (box_max) box_max[a] = s->bmax[a]; }
+    return SR_OK;
+}
+
+int sr_last_ray_stats(const sr_scene* s, uint64_t out[8]) {
+    if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
+    std::memcpy(out, s->last_stats, sizeof(s->last_stats));
+    return SR_OK;
+}
+
+void sr_make_random_triangles(int32_t seed, int64_t n, double space, double extent, double origin, int32_t opaque,
+                              double* v9, uint32_t* argb) {
+    sr::NetRandom rnd(seed);
+    for (int64_t i = 0; i < n; ++i) {
+        double* p = v9 + 9 * i;
+        for (int a = 0; a < 3; ++a) p[a] = rnd.next_double() * space + origin;          // v1 = MakeRandomVector(space)
+        for (int a = 0; a < 3; ++a) p[3 + a] = p[a] + rnd.next_double() * extent;       // v2 = v1 + MakeRandomVector(extent)
+        for (int a = 0; a < 3; ++a) p[6 + a] = p[a] + rnd.next_double() * extent;       // v3 = v1 + MakeRandomVector(extent)
+        uint32_t c = (uint32_t)rnd.next();                                              // (uint)random.Next()
+        argb[i] = opaque ? (0xFF000000u | (c & 0xFFFFFFu)) : c;
+    }
+}
+
+int sr_last_kernel_times(sr_scene* s, sr_kernel_time* out, int32_t cap) {
+    if (!s || !out || cap <= 0 || !s->ev_made) return 0;
+    if (use_device(s)) return 0;
+    int n = 0;
+    for (int k = 0; k < sr::K_COUNT && n < cap; ++k) {
+        if (!s->ev_launches[k]) continue;
+        if (hipEventSynchronize(s->ev[k][1]) != hipSuccess) continue;
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, s->ev[k][0], s->ev[k][1]) != hipSuccess) continue;
+        out[n].name = sr::kernel_name(k);
+        out[n].ms = ms;
+        out[n].launches = s->ev_launches[k];
+        ++n;
+    }
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,56 @@
+// sr_device.h -- interface between the C-ABI layer (sr_api.cpp) and the gfx950 kernels (sr_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sr_types.h"
+
+namespace sr {
+
+// Device-resident scene (all pointers are HBM addresses on the scene's device).
+struct DevScene {
+    const Rec128*  tris;        // model triangles in TriangleIndex order
+    int32_t        ntris;
+    const Rec128*  extra;       // ExtraGeometryToRaytrace, insertion order
+    int32_t        nextra;
+    // reference tree
+    const RefNode* rnodes;
+    const LeafBox* rboxes;
+    const int32_t* rleaf;
+    int32_t        rdepth;      // TreeDepth (stack bound)
+    // own BVH
+    const BvhNode* bnodes;
+    const Rec128*  btris;       // triangle records gathered in leaf order (aux = TriangleIndex)
+    int32_t        bdepth;
+    RootBox        root;
+};
+
+enum KernelId { K_RENDER = 0, K_TRACE = 1, K_PRIMARY = 2, K_SHADOW = 3, K_RESOLVE = 4, K_COUNT = 5 };
+const char* kernel_name(int id);
+
+struct RenderLaunch {
+    DevScene    sc;
+    FrameConst  fc;
+    int32_t     mode;           // SR_MODE_*
+    const double* offsets;      // device [shadow_samples][3]
+    const int32_t* row_map;     // device [num_rows]: image row of each compact row
+    uint32_t*   pixels;         // device output
+    unsigned long long* stats;  // device [8] or nullptr: primary {rays, tri tests, nodes, leaves}, secondary {same}
+    hipStream_t stream;
+};
+
+// The one-kernel renderer: ray generation, traversal, shading, inline shadow rays, sub-pixel resolve.
+hipError_t launch_render(const RenderLaunch& L);
+
+struct TraceLaunch {
+    DevScene sc;
+    int32_t  mode;              // SR_MODE_*
+    bool     with_extra;        // root geometry of the chain (extra + model)
+    int64_t  n;
+    const double* starts; const double* dirs;      // device [n][3]
+    uint8_t* hit; double* ray_frac; double* pos; double* normal; uint32_t* color; int32_t* tri; int32_t* counters;
+    hipStream_t stream;
+};
+hipError_t launch_trace(const TraceLaunch& L);
+
+}  // namespace sr

@@ -1,0 +1,85 @@
+// sr_types.h -- records shared by the host scene builder and the gfx950 kernels.
+// Layouts are the HBM layouts described in DESIGN.md ("Data layout in HBM").
+#pragma once
+#include <stdint.h>
+
+namespace sr {
+
+// 128-byte primitive record, 16-byte aligned so a lane reads it as 8 x global_load_dwordx4 and a wave
+// broadcast-reads it from LDS with ds_read_b128.
+//
+// Triangle (Raytrace/Triangle.cs:29-57 precomputed):
+//   p[0..2] plane unit normal   p[3] plane originDist     p[4..6] vertex1
+//   p[7..9] edge2Perp           p[10] edge1 . edge2Perp   p[11..13] edge1Perp   p[14] edge2 . edge1Perp
+//   aux = TriangleIndex
+// Sphere (Raytrace/Sphere.cs:26-33):   p[0..2] centre  p[3] radius  p[4] radiusSqr          aux = kind 0
+// Plane  (Raytrace/Plane.cs:22-29):    p[0..2] unit normal  p[3] originDist                 aux = kind 1
+// Extra triangles use the triangle layout with aux = kind 2.
+struct alignas(16) Rec128 {
+    double   p[15];
+    uint32_t color;
+    int32_t  aux;
+};
+static_assert(sizeof(Rec128) == 128, "Rec128 must be 128 bytes");
+
+// Reference tree node (SpatialSubdivision.Node flattened, SpatialSubdivision.cs:22-46), 32 B.
+//   internal: axis 0..2, split = splittingPlane.DistanceToOrigin, a = normalSide index, b = backSide index
+//   leaf:     axis = -1, a = first entry in the leaf triangle-index list, b = count, box = leaf box index
+struct alignas(16) RefNode {
+    double  split;
+    int32_t axis;
+    int32_t a;
+    int32_t b;
+    int32_t box;
+    int32_t pad[2];
+};
+static_assert(sizeof(RefNode) == 32, "RefNode must be 32 bytes");
+
+// Leaf bounding box with the reference's +-1e-10 slack already applied on the host
+// (AxisAlignedBox.ContainsPoint, AxisAlignedBox.cs:143-149): lo = min - eps, hi = max + eps. 48 B.
+struct LeafBox {
+    double lo[3];
+    double hi[3];
+};
+
+// Own BVH node, 64 B = one 64-byte line: both children's boxes in fp32 (conservatively padded, in
+// coordinates relative to the root-box centre) + child links.  n? > 0: leaf, c? = first record in the
+// leaf-ordered triangle array; n? == 0: inner node index c?; n? < 0: empty child.
+struct alignas(16) BvhNode {
+    float   lo0[3], hi0[3];
+    float   lo1[3], hi1[3];
+    int32_t c0, c1;
+    int32_t n0, n1;
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// Root box as the clip needs it (AxisAlignedBox.cs:16-28,143-149)
+struct RootBox {
+    double min[3], max[3];       // model.Min / model.Max
+    double lo[3], hi[3];         // min - 1e-10, max + 1e-10
+    double pd[6];                // originDist of the six planes (-x,-y,-z at min; +x,+y,+z at max)
+    double centre[3];            // (min + max) * 0.5, for the BVH's fp32 frame
+};
+
+// Per-frame constants, passed by value as a kernel argument (lives in SGPRs / the kernarg segment).
+struct FrameConst {
+    int32_t  width, height;
+    int32_t  first_row;          // first image row of this launch's row table entry 0 (see row_map)
+    int32_t  num_rows;           // rows rendered by this launch (compact count when strips are on)
+    int32_t  sub_pixel_res;
+    uint32_t background;         // already OR-ed with 0xFF000000
+    uint32_t flags;
+    int32_t  shadow_samples;
+    int32_t  strip_rows, strip_count, strip_index;
+    int32_t  start_row;
+    double   t[12];              // Instance._transform rows 0..2
+    double   it[12];             // Instance._inverseTransform rows 0..2
+    double   position_z, fov_depth, focal_depth, focal_blur_strength;
+    double   ambient, shininess;
+    double   light_dir_view[3], light_pos_view[3];
+    double   light_dir_model[3], light_pos_model[3];
+    double   start_world[3];     // R^-1 * (0,0,-Position.z), Renderer.cs:1717
+    double   aspect;             // (double)height / (double)width, Renderer.cs:621
+};
+
+}  // namespace sr

@@ -1,0 +1,388 @@
+"""Host-side mirror of the reference's public raytrace API (Engine3D.Renderer / Instance / Model /
+GeometryCollection / Sphere / Plane / Triangle / Vector / Color), over the C ABI of include/softray.h.
+
+Same names, same argument meaning, same error behaviour as the C# (file:line cites below), so the
+parity tests read like Engine3D-Tests/Raytrace/RendererTests.cs.  Nothing is computed here: every
+ray is traced by libsoftray_hip.so on the MI355X; this module only copies public fields into an
+`sr_frame` exactly the way Renderer.RaytraceGeometry does (Renderer.cs:1501-1687).
+
+Out of scope: the scan-line rasteriser, static-shadow / AO / light-field caches,
+path tracing and voxels.  Asking for them raises NotImplementedError instead of silently differing.
+"""
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import (F_FOCAL_BLUR, F_POINT_LIGHT, F_SHADING, F_SHADOWS, F_SPECULAR, MODE_BRUTE, MODE_BVH,
+                   MODE_REF_TREE, Frame)
+from .scene import GpuScene, default_fov_depth, instance_matrices
+
+
+def _to_byte(d):
+    """C# unchecked (byte)(double)."""
+    if not (-2147483649.0 < d < 2147483648.0):
+        return 0
+    return int(d) & 0xff
+
+
+class Vector:
+    """Engine3D.Vector (Vector.cs:9-197): three doubles."""
+    __slots__ = ("x", "y", "z")
+
+    def __init__(self, x=0.0, y=0.0, z=0.0):
+        self.x, self.y, self.z = float(x), float(y), float(z)
+
+    def __iter__(self):
+        return iter((self.x, self.y, self.z))
+
+    def __sub__(self, o):
+        return Vector(self.x - o.x, self.y - o.y, self.z - o.z)
+
+    def __mul__(self, s):
+        return Vector(self.x * s, self.y * s, self.z * s)
+
+    def Normalise(self):                      # Vector.cs:177-185: multiply by 1/len
+        ln = math.sqrt(self.x * self.x + self.y * self.y + self.z * self.z)
+        inv = 1.0 / ln
+        self.x *= inv
+        self.y *= inv
+        self.z *= inv
+
+    def __repr__(self):
+        return "%r,%r,%r" % (self.x, self.y, self.z)
+
+
+class Color:
+    """Engine3D.Color (Color.cs:5-137)."""
+    __slots__ = ("r", "g", "b")
+
+    def __init__(self, r, g, b):
+        self.r, self.g, self.b = float(r), float(g), float(b)
+
+    def ToARGB(self):                         # Color.cs:105-111
+        return (255 << 24) + (_to_byte(self.r * 255.0) << 16) + (_to_byte(self.g * 255.0) << 8) + _to_byte(self.b * 255.0)
+
+
+Color.Black = Color(0.0, 0.0, 0.0); Color.White = Color(1.0, 1.0, 1.0); Color.Grey = Color(0.5, 0.5, 0.5)
+Color.Red = Color(1.0, 0.0, 0.0); Color.Green = Color(0.0, 1.0, 0.0); Color.Blue = Color(0.0, 0.0, 1.0)
+Color.Yellow = Color(1.0, 1.0, 0.0); Color.Orange = Color(1.0, 0.5, 0.0); Color.Brown = Color(0.5, 0.25, 0.0)
+Color.Pink = Color(1.0, 0.0, 1.0); Color.Cyan = Color(0.0, 1.0, 1.0)
+
+
+class Sphere:
+    """Raytrace.Sphere (Sphere.cs:26-33); Color defaults to white."""
+
+    def __init__(self, center, radius, Color=Color.White):
+        if not radius > 0:
+            raise ValueError("radius must be > 0")       # Contract.Requires(radius > 0)
+        self.center, self.radius, self.Color = center, float(radius), Color
+
+    def _prim(self):
+        return (0, self.Color.ToARGB(), [self.center.x, self.center.y, self.center.z, self.radius])
+
+
+class Plane:
+    """Raytrace.Plane (Plane.cs:22-29): one-sided."""
+
+    def __init__(self, point, normal, Color=Color.White):
+        self.point, self.normal, self.Color = point, normal, Color
+
+    def _prim(self):
+        return (1, self.Color.ToARGB(), list(self.point) + list(self.normal))
+
+
+class Triangle:
+    """Raytrace.Triangle (Triangle.cs:29-57): one-sided, packed ARGB colour."""
+
+    def __init__(self, v1, v2, v3, color):
+        self.v1, self.v2, self.v3, self.color = v1, v2, v3, int(color)
+
+    def _prim(self):
+        return (2, self.color, list(self.v1) + list(self.v2) + list(self.v3))
+
+
+class GeometryCollection:
+    """Raytrace.GeometryCollection (GeometryCollection.cs:8-31): ordered list of primitives."""
+
+    def __init__(self):
+        self._items = []
+
+    def Add(self, geometry):
+        self._items.append(geometry)
+
+    @property
+    def Count(self):
+        return len(self._items)
+
+    def __getitem__(self, i):
+        return self._items[i]
+
+
+class Model:
+    """Engine3D.Model after Load3ds + PostProcessGeometry (Model.cs:522-653,750-831): triangles in the
+    unit cube.  `FromTriangles` is the programmatic route (like Cloth.cs)."""
+
+    def __init__(self):
+        self.LoadingComplete = False
+        self.LoadingError = False
+        self._v9 = None
+        self._argb = None
+        self.Min = None
+        self.Max = None
+
+    @staticmethod
+    def FromTriangles(v9, argb, box_min, box_max):
+        m = Model()
+        m._v9 = np.ascontiguousarray(v9, dtype=np.float64).reshape(-1, 3, 3)
+        m._argb = np.ascontiguousarray(argb, dtype=np.uint32)
+        m.Min, m.Max = Vector(*box_min), Vector(*box_max)
+        m.LoadingComplete = True
+        return m
+
+    def Load3dsModelFromStream(self, stream):
+        data = stream.read()
+        tmp = GpuScene(device=-1)             # host-only handle: parsing is host work
+        try:
+            tmp.load_3ds(data)                # raises SoftrayError(SR_ERR_FORMAT) like FormatException
+            v9, argb, bmin, bmax = tmp.get_triangles()
+        except Exception:
+            self.LoadingError = True          # Model.cs:199
+            raise
+        finally:
+            tmp.close()
+        self._v9, self._argb = v9, argb
+        self.Min, self.Max = Vector(*bmin), Vector(*bmax)
+        self.LoadingComplete = True
+        self.LoadingError = False
+
+    @property
+    def Triangles(self):
+        return self._v9
+
+
+class Instance:
+    """Engine3D.Instance (Instance.cs:21-51)."""
+
+    def __init__(self, model, Position=None, Yaw=0.0, Pitch=0.0, Roll=0.0):
+        if model is None:
+            raise ValueError("model != null")                      # Contract.Requires(model != null)
+        self.Model = model
+        self.FieldOfViewDepth = 0.5                                # 90 degree FOV until Render() sets it
+        self.Position = Position if Position is not None else Vector(0.0, 0.0, 1.5)
+        self.Yaw, self.Pitch, self.Roll = Yaw, Pitch, Roll
+
+
+class Renderer:
+    """Engine3D.Renderer, raytrace half.  Public fields keep the C# names (Renderer.cs:35-139)."""
+
+    def __init__(self, device=0):
+        # lighting (view space), Renderer.cs:207-217
+        self.ambientLight_intensity = 0.1
+        d = Vector(-1, -1, 1)
+        d.Normalise()
+        self.directionalLight_dir = d
+        self.positionalLight_pos = Vector(0.0, 0.0, 1.5) - d * 2
+        self.specularLight_shininess = 100.0
+        self.pointLighting = True
+        self.specularLighting = True
+        # raytracing options, Renderer.cs:75-92
+        self.rayTrace = False
+        self.rayTraceShading = True
+        self.rayTraceShadows = False
+        self.rayTraceShadowsStatic = False
+        self.rayTraceAmbientOcclusion = False
+        self.rayTraceLightField = False
+        self.rayTraceSubdivision = True
+        self.rayTracePathTracing = False
+        self.rayTraceVoxels = False
+        self.rayTraceFocalBlur = True
+        self.rayTraceFocalDepth = 1.5
+        self.rayTraceFocalBlurStrength = 10.0
+        self.rayTraceConcurrency = 4          # kept for API compatibility; the GPU renders exact row ranges
+        self.rayTraceSubPixelRes = 1
+        self.rayTraceRandomSeed = 1234567890
+        self.rayTraceStartRow = 0
+        self.rayTraceEndRow = 0
+        # MI355X additions (not in the reference): which acceleration structure the device walks
+        self.gpuTraceMode = None              # None: REF_TREE if rayTraceSubdivision else BRUTE; or MODE_BVH
+        self.gpuTreeMaxDepth = 0              # 0 => SpatialSubdivision defaults 15 / 25
+        self.gpuTreeMaxGeometryPerNode = 0
+        self.Instances = []
+        self.ExtraGeometryToRaytrace = GeometryCollection()
+        self.CachePath = "./cache"
+        self._backgroundColor = 0
+        self._fieldOfViewDepth = default_fov_depth()               # Renderer.cs:97-101
+        self._width = self._height = 1
+        self._pixels = np.zeros(1, dtype=np.int32)
+        self._modelVolatile = None
+        self._model = None
+        self._scene = GpuScene(device)
+        self._built = set()
+        self._sceneModel = None
+        self._extraSig = None
+        self._stats = np.zeros(4, dtype=np.uint64)
+
+    # ---- properties ----
+    @property
+    def BackgroundColor(self):
+        return self._backgroundColor
+
+    @BackgroundColor.setter
+    def BackgroundColor(self, value):
+        self._backgroundColor = int(value) & 0x00FFFFFF           # Renderer.cs:308-321
+
+    @property
+    def BackgroundColorWithAlpha(self):
+        return self._backgroundColor | 0xFF000000
+
+    @property
+    def Model(self):
+        return self._modelVolatile
+
+    @Model.setter
+    def Model(self, value):                                        # Renderer.cs:349-364
+        self._modelVolatile = value
+        if value is not None:
+            value.LoadingComplete = True
+            value.LoadingError = False
+
+    NumRaysFired = property(lambda self: int(self._stats[0]))     # Renderer.cs:465-504
+    NumGeometryTests = property(lambda self: int(self._stats[1]))
+    NumNodeVisits = property(lambda self: int(self._stats[2]))
+    NumLeafNodeVisits = property(lambda self: int(self._stats[3]))
+    RenderingSurfaceWidth = property(lambda self: self._width)
+    RenderingSurfaceHeight = property(lambda self: self._height)
+
+    # ---- public methods ----
+    def SetRenderingSurface(self, width, height, pixels):
+        """Renderer.cs:593-626: the caller owns `pixels` (int32[>= width*height]); it is written in place."""
+        pixels = np.asarray(pixels)
+        if pixels.dtype != np.int32 or pixels.size < width * height or not pixels.flags["C_CONTIGUOUS"]:
+            raise ValueError("pixels must be a contiguous int32 array of at least width*height elements")
+        same = (width == self._width and height == self._height)
+        self._pixels = pixels
+        if not same:
+            self._width, self._height = width, height
+            self.rayTraceStartRow = 0
+            self.rayTraceEndRow = height - 1
+
+    def Load3dsModelFromStream(self, stream):                      # Renderer.cs:629-635
+        self._modelVolatile = Model()
+        self._modelVolatile.Load3dsModelFromStream(stream)
+
+    def HasModelCompletedLoading(self):
+        return self._modelVolatile is not None and self._modelVolatile.LoadingComplete
+
+    def HasModelLoadFailed(self):
+        return self._modelVolatile is not None and self._modelVolatile.LoadingError
+
+    def _PinModel(self):                                           # Renderer.cs:791-810
+        if self._modelVolatile is None:
+            return False
+        if self._modelVolatile.LoadingComplete:
+            self._modelVolatile.LoadingComplete = False
+            self._model = self._modelVolatile
+            return True
+        return self._model is not None
+
+    def _mode(self):
+        if self.gpuTraceMode is not None:
+            return self.gpuTraceMode
+        return MODE_REF_TREE if self.rayTraceSubdivision else MODE_BRUTE
+
+    def PreCalculate(self):
+        """Renderer.cs:673-699: MakeRayTracableGeometry_simple / _subdivided, here = upload + build on demand."""
+        if not self._PinModel():
+            raise RuntimeError("PreCalculate: no model is loading (the reference would spin forever, Renderer.cs:676-679)")
+        if not self.rayTrace:
+            return
+        if self._sceneModel is not self._model:
+            m = self._model
+            self._scene.set_triangles(m._v9, m._argb, list(m.Min), list(m.Max))
+            self._sceneModel = m
+            self._built = set()
+        mode = self._mode()
+        if mode != MODE_BRUTE and mode not in self._built:
+            self._scene.build((mode,), self.gpuTreeMaxDepth, self.gpuTreeMaxGeometryPerNode)
+            self._built.add(mode)
+
+    def Render(self):
+        """Renderer.cs:701-778."""
+        if not self.rayTrace:
+            raise NotImplementedError("the scan-line rasteriser is out of scope of the MI355X hot path (SURVEY.md 2, row 21)")
+        if not self._PinModel():
+            return                                                 # silently, Renderer.cs:736-739
+        for name in ("rayTraceShadowsStatic", "rayTraceAmbientOcclusion", "rayTraceLightField", "rayTracePathTracing", "rayTraceVoxels"):
+            if getattr(self, name) and (name != "rayTraceShadowsStatic" or self.rayTraceShadows):
+                raise NotImplementedError("%s is out of scope (RNG-order / racy-cache dependent in the reference; SURVEY.md 2)" % name)
+        for instance in self.Instances:
+            instance.FieldOfViewDepth = self._fieldOfViewDepth     # Renderer.cs:749
+            self._RaytraceGeometry(instance)
+
+    def Dispose(self):                                             # Renderer.cs:236-256
+        if self._scene is not None:
+            self._scene.close()
+            self._scene = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.Dispose()
+
+    # ---- the part of RaytraceGeometry that stays on the host: copy fields into sr_frame ----
+    def BuildFrame(self, instance):
+        f = Frame()
+        f.width, f.height = self._width, self._height
+        f.start_row, f.end_row = self.rayTraceStartRow, self.rayTraceEndRow
+        f.sub_pixel_res = self.rayTraceSubPixelRes
+        f.background_argb = self._backgroundColor
+        flags = 0
+        if self.rayTraceShading:
+            flags |= F_SHADING
+        if self.rayTraceShadows:
+            flags |= F_SHADOWS
+        if self.rayTraceFocalBlur:
+            flags |= F_FOCAL_BLUR
+        if self.pointLighting:
+            flags |= F_POINT_LIGHT
+        if self.specularLighting:
+            flags |= F_SPECULAR
+        f.flags = flags
+        f.random_seed = self.rayTraceRandomSeed
+        f.shadow_samples = 0
+        f.trace_mode = self._mode()
+        t, it = instance_matrices(list(instance.Position), instance.Yaw, instance.Pitch, instance.Roll)   # Instance.cs:134-135
+        for i in range(12):
+            f.transform[i] = t[i]
+            f.inv_transform[i] = it[i]
+        f.position_z = instance.Position.z
+        f.fov_depth = instance.FieldOfViewDepth
+        f.focal_depth = self.rayTraceFocalDepth
+        f.focal_blur_strength = self.rayTraceFocalBlurStrength
+        f.ambient = self.ambientLight_intensity
+        f.shininess = self.specularLight_shininess
+        for i, v in enumerate(self.directionalLight_dir):
+            f.light_dir_view[i] = v
+        for i, v in enumerate(self.positionalLight_pos):
+            f.light_pos_view[i] = v
+        f.area_light_offsets = None
+        return f
+
+    def _RaytraceGeometry(self, instance):                         # Renderer.cs:1501-1687
+        self.PreCalculate()
+        sig = tuple((type(g).__name__, g._prim()[1], tuple(g._prim()[2])) for g in self.ExtraGeometryToRaytrace._items)
+        if sig != self._extraSig:
+            self._scene.set_extra([g._prim() for g in self.ExtraGeometryToRaytrace._items])
+            self._extraSig = sig
+        # Renderer.cs:1652-1653
+        self.rayTraceStartRow = min(max(0, self.rayTraceStartRow), self._height - 1)
+        self.rayTraceEndRow = min(max(0, self.rayTraceEndRow), self._height - 1)
+        frame = self.BuildFrame(instance)
+        view = self._pixels.reshape(-1)[: self._width * self._height]
+        _, self._stats = self._scene.render(frame, out=view, stats=True)
+
+
+__all__ = ["Renderer", "Instance", "Model", "GeometryCollection", "Sphere", "Plane", "Triangle", "Vector", "Color",
+           "MODE_REF_TREE", "MODE_BRUTE", "MODE_BVH"]

@@ -1,0 +1,152 @@
+"""Thin object wrapper over the C ABI: one `GpuScene` per reference `Renderer` (what PreCalculate()
+keeps: geometry_simple, geometry_subdivided, ExtraGeometryToRaytrace)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Frame, KernelTime, Prim
+
+
+class SoftrayError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("softray error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _check(rc):
+    if rc != 0:
+        raise SoftrayError(rc, _lib.lib().sr_last_error().decode())
+
+
+class GpuScene:
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        _check(_lib.lib().sr_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().sr_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- PreCalculate() ----
+    def set_triangles(self, v9, argb, bmin, bmax):
+        v9 = np.ascontiguousarray(v9, dtype=np.float64).reshape(-1, 9)
+        argb = np.ascontiguousarray(argb, dtype=np.uint32)
+        bmin = np.ascontiguousarray(bmin, dtype=np.float64)
+        bmax = np.ascontiguousarray(bmax, dtype=np.float64)
+        _check(_lib.lib().sr_set_triangles(self._h, _p(v9), _p(argb), v9.shape[0], _p(bmin), _p(bmax)))
+
+    def load_3ds(self, data):
+        buf = np.frombuffer(bytes(data), dtype=np.uint8)
+        _check(_lib.lib().sr_load_3ds(self._h, _p(buf), buf.size))
+
+    def num_triangles(self):
+        return int(_lib.lib().sr_num_triangles(self._h))
+
+    def get_triangles(self):
+        n = self.num_triangles()
+        v9 = np.zeros((n, 3, 3)); argb = np.zeros(n, dtype=np.uint32); bmin = np.zeros(3); bmax = np.zeros(3)
+        _check(_lib.lib().sr_get_triangles(self._h, _p(v9), _p(argb), _p(bmin), _p(bmax)))
+        return v9, argb, bmin, bmax
+
+    def set_extra(self, prims):
+        arr = (Prim * max(1, len(prims)))()
+        for i, (kind, argb, params) in enumerate(prims):
+            arr[i].kind = kind
+            arr[i].argb = argb
+            for j, v in enumerate(params):
+                arr[i].p[j] = v
+        _check(_lib.lib().sr_set_extra_geometry(self._h, arr, len(prims)))
+
+    def build(self, modes=(_lib.MODE_REF_TREE,), max_depth=0, max_per_leaf=0):
+        mask = 0
+        for m in modes:
+            mask |= 1 << m
+        _check(_lib.lib().sr_build(self._h, mask, max_depth, max_per_leaf))
+
+    def tree_stats(self):
+        out = np.zeros(4, dtype=np.int32)
+        _check(_lib.lib().sr_tree_stats(self._h, _p(out)))
+        return tuple(int(x) for x in out)
+
+    # ---- Render() ----
+    @staticmethod
+    def pixel_count(frame):
+        return int(_lib.lib().sr_frame_pixel_count(C.byref(frame)))
+
+    def render(self, frame, out=None, stats=True):
+        n = self.pixel_count(frame)
+        pixels = out if out is not None else np.zeros(n, dtype=np.int32)
+        st = np.zeros(4, dtype=np.uint64) if stats else None
+        _check(_lib.lib().sr_render(self._h, C.byref(frame), _p(pixels), _p(st)))
+        return pixels.view(np.uint32), st
+
+    def render_device(self, frame, d_pixels_ptr, stream=0, d_stats_ptr=None):
+        _check(_lib.lib().sr_render_device(self._h, C.byref(frame), C.c_void_p(d_pixels_ptr), C.c_void_p(stream),
+                                           C.c_void_p(d_stats_ptr) if d_stats_ptr else None))
+
+    def ray_stats(self):
+        """primary {rays, tests, nodes, leaves} + secondary {rays, tests, nodes, leaves} of the last render(stats=True)."""
+        out = np.zeros(8, dtype=np.uint64)
+        _check(_lib.lib().sr_last_ray_stats(self._h, _p(out)))
+        return out
+
+    def kernel_times(self):
+        arr = (KernelTime * 8)()
+        n = _lib.lib().sr_last_kernel_times(self._h, arr, 8)
+        return {arr[i].name.decode(): (float(arr[i].ms), int(arr[i].launches)) for i in range(n)}
+
+    # ---- IRayIntersectable.IntersectRay, batched ----
+    def trace(self, target, starts, dirs, counters=False):
+        starts = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float64).reshape(-1, 3)
+        n = starts.shape[0]
+        res = dict(hit=np.zeros(n, dtype=np.uint8), ray_frac=np.zeros(n), pos=np.zeros((n, 3)),
+                   normal=np.zeros((n, 3)), color=np.zeros(n, dtype=np.uint32), tri_index=np.zeros(n, dtype=np.int32))
+        cnt = np.zeros((n, 3), dtype=np.int32) if counters else None
+        _check(_lib.lib().sr_trace_rays(self._h, int(target), n, _p(starts), _p(dirs), _p(res["hit"]), _p(res["ray_frac"]),
+                                        _p(res["pos"]), _p(res["normal"]), _p(res["color"]), _p(res["tri_index"]), _p(cnt)))
+        if counters:
+            res["counters"] = cnt
+        return res
+
+
+def make_random_triangles(n, seed=12345, space=100.0, extent=10.0, origin=0.0, opaque=False):
+    """SpatialSubdivisionTests.MakeRandomTriangles with the library's System.Random port."""
+    v9 = np.zeros((int(n), 3, 3))
+    argb = np.zeros(int(n), dtype=np.uint32)
+    _lib.lib().sr_make_random_triangles(int(seed), int(n), float(space), float(extent), float(origin), int(bool(opaque)),
+                                        _p(v9), _p(argb))
+    return v9, argb
+
+
+def unit_cube_scene(n, seed=12345):
+    """SURVEY 8d synthetic scene (configs 3/4): v1 in [-0.5,0.45]^3, extents U[0,0.05]^3, box [-0.5,0.5]^3."""
+    v9, argb = make_random_triangles(n, seed, space=0.95, extent=0.05, origin=-0.5, opaque=True)
+    return v9, argb, np.array([-0.5] * 3), np.array([0.5] * 3)
+
+
+def instance_matrices(position, yaw, pitch, roll):
+    pos = np.asarray(position, dtype=np.float64)
+    t = np.zeros(12); it = np.zeros(12)
+    _lib.lib().sr_instance_matrices(_p(pos), float(yaw), float(pitch), float(roll), _p(t), _p(it))
+    return t, it
+
+
+def default_fov_depth():
+    return float(_lib.lib().sr_default_fov_depth())
+
+
+def area_light_offsets(seed, count=100):
+    out = np.zeros((count, 3))
+    _lib.lib().sr_area_light_offsets(int(seed), int(count), _p(out))
+    return out

@@ -1,0 +1,184 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
+same inputs and against the reference's golden BMPs.  Bar: bit-exact ARGB / bit-exact doubles."""
+import os
+
+import numpy as np
+import pytest
+
+import softray_amd as sa
+from helpers import (GOLDEN, c1_spheres, load_obj3ds, make_frame, orc, random_triangles, read_bmp_rgb, unit_cube_scene)
+from test_oracle import GOLDENS, TREE_BOX, golden_rgb
+
+pytestmark = pytest.mark.gpu
+NCPU = os.cpu_count() or 8
+
+
+def as_sr(frame, mode=None):
+    f = sa.Frame.from_buffer_copy(bytes(frame))
+    if mode is not None:
+        f.trace_mode = mode
+    return f
+
+
+@pytest.fixture(scope="module")
+def obj_pair():
+    v9, argb, bmin, bmax = load_obj3ds()
+    g = sa.GpuScene(0)
+    g.load_3ds(open(os.path.join(GOLDEN, "obj.3ds"), "rb").read())      # the product's own loader
+    g.build((sa.MODE_REF_TREE, sa.MODE_BVH))
+    o = orc.Scene()
+    o.set_triangles(v9, argb, bmin, bmax)
+    assert o.build_tree() == 0
+    return g, o
+
+
+@pytest.mark.parametrize("name,res,kw", GOLDENS, ids=["%s_%d" % (g[0], g[1]) for g in GOLDENS])
+def test_goldens_on_gpu(obj_pair, name, res, kw):
+    g, o = obj_pair
+    f = make_frame(res, **kw)
+    got, gstats = g.render(as_sr(f))
+    want, ostats = o.render(f, threads=NCPU)
+    assert int(np.count_nonzero((got.reshape(res, res) & 0xFFFFFF) != golden_rgb(name, res))) == 0
+    assert np.array_equal(got, want)
+    assert np.array_equal(gstats, ostats)            # NumRaysFired / NumGeometryTests / NumNodeVisits / NumLeafNodeVisits
+
+
+@pytest.mark.parametrize("mode,omode", [(sa.MODE_BRUTE, orc.MODE_BRUTE), (sa.MODE_BVH, orc.MODE_NEAREST)])
+@pytest.mark.parametrize("kw", [dict(), dict(shadows=True), dict(shadows=True, focal_blur=True, sub_pixel_res=2),
+                                dict(shading=False, sub_pixel_res=3), dict(point_light=False, shadows=True),
+                                dict(specular=False)])
+def test_modes_match_oracle(obj_pair, mode, omode, kw):
+    g, o = obj_pair
+    f = make_frame(96, 64, mode=omode, **kw)
+    got, _ = g.render(as_sr(f, mode))
+    want, _ = o.render(f, threads=NCPU)
+    assert np.array_equal(got, want)
+    ref, _ = o.render(make_frame(96, 64, **kw), threads=NCPU)
+    assert np.array_equal(got, ref)                  # and all three modes give the reference-tree image
+
+
+def _rays(rnd, n, outside_in):
+    u = rnd.NextDoubles(6 * n).reshape(n, 6)
+    if outside_in:
+        starts = u[:, 0:3] * 1000.0
+        return starts, u[:, 3:6] * 100.0 - starts
+    return u[:, 0:3] * 100.0, 2.0 * u[:, 3:6] + -1.0
+
+
+@pytest.mark.parametrize("n_tris,max_depth,max_geom,seed,n_rays,outside_in", [
+    (100, 10, 5, 12345, 100000, False),      # TreeCorrectness1
+    (20, 10, 1, 123456, 100000, False),      # TreeCorrectness2
+    (20, 10, 1, 123456, 100000, True),       # TreeCorrectness_OutsideIn
+    (100, 10, 5, 1234567, 265896, False),    # ..._EnsureIntersectionCheckedAgainstTreeNodeBoundingBox
+    (10000, 10, 5, 1234567, 2000, False),    # ...BoundingBox2 (34 rays in the reference; more here)
+    (1000, 10, 5, 12345, 50000, True),
+])
+def test_intersect_ray_batches(n_tris, max_depth, max_geom, seed, n_rays, outside_in):
+    """IRayIntersectable.IntersectRay on the device == oracle, bit for bit, for the tree, brute force and the BVH."""
+    v9, argb, rnd = random_triangles(n_tris, seed=seed)
+    g = sa.GpuScene(0)
+    g.set_triangles(v9, argb, *TREE_BOX)
+    g.build((sa.MODE_REF_TREE, sa.MODE_BVH), max_depth, max_geom)
+    o = orc.Scene()
+    o.set_triangles(v9, argb, *TREE_BOX)
+    assert o.build_tree(max_depth, max_geom) == 0
+    assert g.tree_stats() == o.tree_stats()
+    starts, dirs = _rays(rnd, n_rays, outside_in)
+    for target, otarget in ((sa.MODE_REF_TREE, 1), (sa.MODE_BRUTE, 0), (sa.MODE_BVH, 3)):
+        if target == sa.MODE_BRUTE and n_tris > 1000:
+            continue
+        a = g.trace(target, starts, dirs, counters=True)
+        b = o.trace(otarget, starts, dirs, counters=True)
+        for key in ("hit", "tri_index", "color", "ray_frac", "pos", "normal"):
+            assert np.array_equal(a[key], b[key]), (target, key)
+        if target != sa.MODE_BVH:
+            assert np.array_equal(a["counters"], b["counters"])
+    assert a["hit"].any()
+
+
+def test_primitive_kats_on_gpu():
+    g = sa.GpuScene(0)
+    g.set_triangles(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], dtype=np.float64), np.array([0xffffffff], dtype=np.uint32),
+                    [-1, -1, -1], [2, 2, 2])
+    r = g.trace(sa.MODE_BRUTE, [[0, 0, 1], [1, 0, 0], [0, 0, -1]], [[0, 0, -1], [0, 0, -1], [0, 0, 1]])
+    assert list(r["hit"]) == [1, 1, 0]               # TriangleTests.cs:45-73
+    assert r["ray_frac"][0] == 1.0 and r["ray_frac"][1] == 0.0
+    assert np.array_equal(r["normal"][0], [0, 0, 1]) and r["color"][0] == 0xffffffff
+
+
+def test_spheres_planes_triangles_extra_geometry():
+    """Config 1: extra geometry (16 spheres) + obj.3DS at depth 3; plus a plane and a triangle."""
+    v9, argb, bmin, bmax = load_obj3ds()
+    prims = c1_spheres()
+    prims.append((1, 0xff808080, [0, -0.45, 0, 0, 1, 0]))
+    prims.append((2, 0xff00ffff, [-0.6, -0.3, 0.2, 0.6, -0.3, 0.2, 0.0, 0.5, 0.2]))
+    g = sa.GpuScene(0); o = orc.Scene()
+    for s in (g, o):
+        s.set_triangles(v9, argb, bmin, bmax)
+        s.set_extra(prims)
+    g.build((sa.MODE_REF_TREE, sa.MODE_BVH)); assert o.build_tree() == 0
+    for kw in (dict(), dict(shadows=True), dict(sub_pixel_res=2, shadows=True, focal_blur=True)):
+        res = 256 if not kw else 96
+        f = make_frame(res, depth=3.0, **kw)
+        want, _ = o.render(f, threads=NCPU)
+        for mode in (sa.MODE_REF_TREE, sa.MODE_BRUTE, sa.MODE_BVH):
+            got, _ = g.render(as_sr(f, mode))
+            assert np.array_equal(got, want), (kw, mode)
+    # ray batches through the root GeometryCollection (sphere rayFrac is a distance: Sphere.cs:164)
+    rnd = orc.Random(99)
+    u = rnd.NextDoubles(6 * 50000).reshape(-1, 6)
+    starts = 4.0 * u[:, :3] - 2.0
+    dirs = (u[:, 3:] - 0.5) - starts * 0.5
+    a = g.trace(sa.TARGET_ROOT | sa.MODE_REF_TREE, starts, dirs)
+    b = o.trace(2, starts, dirs)
+    for key in ("hit", "tri_index", "color", "ray_frac", "pos", "normal"):
+        assert np.array_equal(a[key], b[key]), key
+
+
+def test_random_scene_all_modes_vs_oracle_tree():
+    """Config-3 style scene at a size the oracle finishes in seconds: 50k random triangles, shading + 100-sample shadows."""
+    v9, argb, bmin, bmax = unit_cube_scene(50000)
+    g = sa.GpuScene(0); o = orc.Scene()
+    for s in (g, o):
+        s.set_triangles(v9, argb, bmin, bmax)
+    g.build((sa.MODE_REF_TREE, sa.MODE_BVH)); assert o.build_tree() == 0
+    assert g.tree_stats() == o.tree_stats()
+    f = make_frame(128, depth=1.5, shadows=True)
+    want, ostats = o.render(f, threads=NCPU)
+    got, gstats = g.render(as_sr(f, sa.MODE_REF_TREE))
+    assert np.array_equal(got, want) and np.array_equal(gstats, ostats)
+    got_bvh, _ = g.render(as_sr(f, sa.MODE_BVH))
+    assert np.array_equal(got_bvh, want)
+    assert len(np.unique(want)) > 1000
+
+
+def test_rows_and_strips_on_gpu(obj_pair):
+    g, o = obj_pair
+    full, _ = g.render(as_sr(make_frame(80, 64, shadows=True)))
+    full = full.reshape(64, 80)
+    buf = np.full(64 * 80, 0x12345678, dtype=np.int32)
+    part, _ = g.render(as_sr(make_frame(80, 64, shadows=True, start_row=10, end_row=20)), out=buf)
+    part = part.reshape(64, 80)
+    assert np.array_equal(part[10:21], full[10:21])
+    assert np.all(part[:10] == 0x12345678) and np.all(part[21:] == 0x12345678)   # untouched, like Surface.DrawPixel
+    rebuilt = np.zeros_like(full)
+    for k in range(3):
+        f = as_sr(make_frame(80, 64, shadows=True, strips=(4, 3, k)))
+        px, _ = g.render(f)
+        rows = [r for r in range(64) if (r // 4) % 3 == k]
+        assert g.pixel_count(f) == len(rows) * 80
+        rebuilt[rows] = px.reshape(len(rows), 80)
+    assert np.array_equal(rebuilt, full)
+
+
+def test_error_codes_on_gpu(obj_pair):
+    g, _ = obj_pair
+    f = as_sr(make_frame(16))
+    f.max_bounces = 2
+    with pytest.raises(sa.SoftrayError) as e:
+        g.render(f)
+    assert e.value.code == sa._lib.SR_ERR_UNSUPPORTED
+    g2 = sa.GpuScene(0)
+    with pytest.raises(sa.SoftrayError) as e:
+        g2.render(as_sr(make_frame(16)))
+    assert e.value.code == sa._lib.SR_ERR_NO_MODEL   # Render() without a model draws nothing (Renderer.cs:736-739)
