@@ -175,10 +175,12 @@ int  sr_load_3ds(sr_scene*, const uint8_t* data, size_t len);
 int64_t sr_num_triangles(const sr_scene*);
 int  sr_get_triangles(const sr_scene*, double* v9, uint32_t* argb, double box_min[3], double box_max[3]);
 
-/* timing of the kernels launched by the last sr_render / sr_render_device (HIP events on the launch
- * stream).  names[i] points to a static string.  Returns the number of entries written (<= cap). */
+/* Device time of the library's kernels, measured with one HIP event pair per launch on the launch stream and
+ * accumulated since sr_reset_kernel_times() (or scene creation): out[i] = {static kernel name, total ms,
+ * launches}.  sr_kernel_times waits for the recorded events.  Returns the number of entries (<= cap). */
 typedef struct { const char* name; float ms; int32_t launches; } sr_kernel_time;
-int  sr_last_kernel_times(sr_scene*, sr_kernel_time* out, int32_t cap);
+void sr_reset_kernel_times(sr_scene*);
+int  sr_kernel_times(sr_scene*, sr_kernel_time* out, int32_t cap);
 
 /* Ray statistics of the last sr_render(..., stats != NULL): primary {rays, triangle/primitive tests, nodes
  * visited, leaf nodes visited} followed by the same four for secondary (shadow) rays.  These are the

@@ -979,16 +979,22 @@ int orc_render(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t
     Vec start_World = fc.xf.TransformDirectionReverse(V(0, 0, -fc.xf.positionZ));   /* Renderer.cs:1717 */
 
     int nthreads = threads > 0 ? threads : 1;
-    std::atomic<size_t> nextRow{0};
+    /* work items = 64-pixel chunks of a row (the reference fans out row BLOCKS, Renderer.cs:1659-1670; pixels are
+     * independent, so the partition does not change any pixel) */
+    const int chunk = 64;
+    const size_t chunksPerRow = (size_t)(f->width + chunk - 1) / chunk;
+    std::atomic<size_t> nextItem{0};
     std::vector<Counters> prim(nthreads), sec(nthreads);
     std::vector<int64_t> rays(nthreads, 0);
     auto worker = [&](int tid) {
         for (;;) {
-            size_t i = nextRow.fetch_add(1);
-            if (i >= rows.size()) break;
+            size_t item = nextItem.fetch_add(1);
+            if (item >= rows.size() * chunksPerRow) break;
+            size_t i = item / chunksPerRow;
+            int c0 = (int)(item % chunksPerRow) * chunk, c1 = std::min(f->width, c0 + chunk);
             int row = rows[i];
             int32_t* dst = (f->strip_count > 0) ? pixels + (size_t)i * f->width : pixels + (size_t)row * f->width;
-            for (int col = 0; col < f->width; col++)
+            for (int col = c0; col < c1; col++)
                 dst[col] = (int32_t)RenderPixel(fc, col, row, start_World, prim[tid], sec[tid], rays[tid]);
         }
     };

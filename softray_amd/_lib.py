@@ -23,7 +23,7 @@ SYMBOLS = [
     "sr_create", "sr_destroy", "sr_set_triangles", "sr_set_extra_geometry", "sr_build", "sr_tree_stats",
     "sr_render", "sr_render_device", "sr_frame_pixel_count", "sr_trace_rays", "sr_instance_matrices",
     "sr_default_fov_depth", "sr_area_light_offsets", "sr_load_3ds", "sr_num_triangles", "sr_get_triangles",
-    "sr_last_kernel_times", "sr_last_ray_stats", "sr_make_random_triangles", "sr_last_error", "sr_abi_version",
+    "sr_reset_kernel_times", "sr_kernel_times", "sr_last_ray_stats", "sr_make_random_triangles", "sr_last_error", "sr_abi_version",
 ]
 
 
@@ -98,7 +98,8 @@ def lib():
     L.sr_load_3ds.restype = i32; L.sr_load_3ds.argtypes = [vp, vp, C.c_size_t]
     L.sr_num_triangles.restype = i64; L.sr_num_triangles.argtypes = [vp]
     L.sr_get_triangles.restype = i32; L.sr_get_triangles.argtypes = [vp, vp, vp, vp, vp]
-    L.sr_last_kernel_times.restype = i32; L.sr_last_kernel_times.argtypes = [vp, vp, i32]
+    L.sr_reset_kernel_times.restype = None; L.sr_reset_kernel_times.argtypes = [vp]
+    L.sr_kernel_times.restype = i32; L.sr_kernel_times.argtypes = [vp, vp, i32]
     L.sr_last_ray_stats.restype = i32; L.sr_last_ray_stats.argtypes = [vp, vp]
     L.sr_make_random_triangles.restype = None
     L.sr_make_random_triangles.argtypes = [i32, i64, dbl, dbl, dbl, i32, vp, vp]

@@ -74,10 +74,9 @@ struct sr_scene {
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
     std::vector<double>  offsets_host;
     std::vector<int32_t> rowmap_host;
-    // timing of the last render
-    hipEvent_t ev[sr::K_COUNT][2] = {};
-    bool ev_made = false;
-    int  ev_launches[sr::K_COUNT] = {};
+    // kernel timing: one HIP event pair per launch, accumulated until sr_reset_kernel_times()
+    std::vector<hipEvent_t> ev[sr::K_COUNT];       // [2*i] start, [2*i+1] stop
+    int  ev_used[sr::K_COUNT] = {};
     uint64_t last_stats[8] = {};
 };
 
@@ -189,11 +188,22 @@ int prepare_frame(sr_scene* s, const sr_frame* f, sr::FrameConst& fc) {
     return SR_OK;
 }
 
-int ensure_events(sr_scene* s) {
-    if (s->ev_made) return SR_OK;
-    for (int k = 0; k < sr::K_COUNT; ++k)
-        for (int j = 0; j < 2; ++j) SR_HIP(hipEventCreate(&s->ev[k][j]));
-    s->ev_made = true;
+const int kMaxTimedLaunches = 4096;
+
+// hands out the event pair for the next launch of kernel k (nullptr once the pool is exhausted)
+int next_events(sr_scene* s, int k, hipEvent_t& a, hipEvent_t& b) {
+    a = b = nullptr;
+    if (s->ev_used[k] >= kMaxTimedLaunches) return SR_OK;
+    if ((size_t)(2 * s->ev_used[k] + 2) > s->ev[k].size()) {
+        hipEvent_t e0, e1;
+        SR_HIP(hipEventCreate(&e0));
+        SR_HIP(hipEventCreate(&e1));
+        s->ev[k].push_back(e0);
+        s->ev[k].push_back(e1);
+    }
+    a = s->ev[k][2 * s->ev_used[k]];
+    b = s->ev[k][2 * s->ev_used[k] + 1];
+    s->ev_used[k]++;
     return SR_OK;
 }
 
@@ -202,14 +212,11 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     int rc = prepare_frame(s, f, fc);
     if (rc) return rc;
     if ((rc = sync_geometry(s, (uint32_t)f->trace_mode))) return rc;
-    if ((rc = ensure_events(s))) return rc;
     SR_HIP(s->d_offsets.reserve(s->offsets_host.size() * sizeof(double)));
     SR_HIP(hipMemcpyAsync(s->d_offsets.p, s->offsets_host.data(), s->offsets_host.size() * sizeof(double), hipMemcpyHostToDevice, stream));
     SR_HIP(s->d_rowmap.reserve(std::max<size_t>(1, s->rowmap_host.size()) * sizeof(int32_t)));
     if (!s->rowmap_host.empty())
         SR_HIP(hipMemcpyAsync(s->d_rowmap.p, s->rowmap_host.data(), s->rowmap_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    for (int k = 0; k < sr::K_COUNT; ++k) s->ev_launches[k] = 0;
-
     sr::RenderLaunch L{};
     L.sc = dev_scene(s);
     L.fc = fc;
@@ -219,10 +226,11 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     L.pixels = d_pixels;
     L.stats = d_stats;
     L.stream = stream;
-    SR_HIP(hipEventRecord(s->ev[sr::K_RENDER][0], stream));
+    hipEvent_t e0, e1;
+    if ((rc = next_events(s, sr::K_RENDER, e0, e1))) return rc;
+    if (e0) SR_HIP(hipEventRecord(e0, stream));
     SR_HIP(sr::launch_render(L));
-    SR_HIP(hipEventRecord(s->ev[sr::K_RENDER][1], stream));
-    s->ev_launches[sr::K_RENDER] = 1;
+    if (e1) SR_HIP(hipEventRecord(e1, stream));
     return SR_OK;
 }
 
@@ -258,9 +266,8 @@ void sr_destroy(sr_scene* s) {
                         &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_stats};
         for (DBuf* b : bufs) b->release();
         for (DBuf& b : s->d_io) b.release();
-        if (s->ev_made)
-            for (int k = 0; k < sr::K_COUNT; ++k)
-                for (int j = 0; j < 2; ++j) (void)hipEventDestroy(s->ev[k][j]);
+        for (int k = 0; k < sr::K_COUNT; ++k)
+            for (hipEvent_t e : s->ev[k]) (void)hipEventDestroy(e);
     }
     delete s;
 }
@@ -467,18 +474,30 @@ void sr_make_random_triangles(int32_t seed, int64_t n, double space, double exte
     }
 }
 
-int sr_last_kernel_times(sr_scene* s, sr_kernel_time* out, int32_t cap) {
-    if (!s || !out || cap <= 0 || !s->ev_made) return 0;
+void sr_reset_kernel_times(sr_scene* s) {
+    if (!s) return;
+    for (int k = 0; k < sr::K_COUNT; ++k) s->ev_used[k] = 0;
+}
+
+int sr_kernel_times(sr_scene* s, sr_kernel_time* out, int32_t cap) {
+    if (!s || !out || cap <= 0) return 0;
     if (use_device(s)) return 0;
     int n = 0;
     for (int k = 0; k < sr::K_COUNT && n < cap; ++k) {
-        if (!s->ev_launches[k]) continue;
-        if (hipEventSynchronize(s->ev[k][1]) != hipSuccess) continue;
-        float ms = 0;
-        if (hipEventElapsedTime(&ms, s->ev[k][0], s->ev[k][1]) != hipSuccess) continue;
+        if (!s->ev_used[k]) continue;
+        double total = 0;
+        int ok = 0;
+        for (int i = 0; i < s->ev_used[k]; ++i) {
+            if (hipEventSynchronize(s->ev[k][2 * i + 1]) != hipSuccess) continue;
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, s->ev[k][2 * i], s->ev[k][2 * i + 1]) != hipSuccess) continue;
+            total += ms;
+            ++ok;
+        }
+        if (!ok) continue;
         out[n].name = sr::kernel_name(k);
-        out[n].ms = ms;
-        out[n].launches = s->ev_launches[k];
+        out[n].ms = (float)total;
+        out[n].launches = ok;
         ++n;
     }
     return n;

@@ -100,9 +100,13 @@ class GpuScene:
         _check(_lib.lib().sr_last_ray_stats(self._h, _p(out)))
         return out
 
+    def reset_kernel_times(self):
+        _lib.lib().sr_reset_kernel_times(self._h)
+
     def kernel_times(self):
+        """{kernel: (total ms, launches)} since reset_kernel_times() -- HIP events on the launch stream."""
         arr = (KernelTime * 8)()
-        n = _lib.lib().sr_last_kernel_times(self._h, arr, 8)
+        n = _lib.lib().sr_kernel_times(self._h, arr, 8)
         return {arr[i].name.decode(): (float(arr[i].ms), int(arr[i].launches)) for i in range(n)}
 
     # ---- IRayIntersectable.IntersectRay, batched ----
