@@ -54,7 +54,13 @@ enum {
     SR_F_SHADOWS     = 1u << 1,   /* rayTraceShadows (dynamic) -> ShadowMethod.Enabled (:1632)          */
     SR_F_FOCAL_BLUR  = 1u << 2,   /* rayTraceFocalBlur (only read when sub_pixel_res > 1, :1744-1790)   */
     SR_F_POINT_LIGHT = 1u << 3,   /* pointLighting   (Scene.cs:20)                                      */
-    SR_F_SPECULAR    = 1u << 4    /* specularLighting (Scene.cs:21)                                     */
+    SR_F_SPECULAR    = 1u << 4,   /* specularLighting (Scene.cs:21)                                     */
+    SR_F_SINGLE_KERNEL = 1u << 8, /* library option, not a Renderer field: trace the frame with the one-kernel
+                                     renderer (k_render) instead of the k_primary/k_shadow/k_resolve pipeline.
+                                     Pixels are identical; kept as an independent cross-check               */
+    SR_F_PER_LANE_SHADOWS = 1u << 9 /* library option: trace shadow samples one lane per hit point (k_shadow)
+                                     instead of one wavefront per hit point with a shared shaft walk
+                                     (k_shadow_packet).  Pixels are identical; cross-check                  */
 };
 
 /* how the model's triangles are intersected */

@@ -15,6 +15,8 @@ SR_OK = 0
 SR_ERR_INVALID_ARG, SR_ERR_OUT_OF_RANGE, SR_ERR_NO_MODEL, SR_ERR_NOT_BUILT = -1, -2, -3, -4
 SR_ERR_UNSUPPORTED, SR_ERR_NO_DEVICE, SR_ERR_HIP, SR_ERR_FORMAT = -5, -6, -7, -8
 F_SHADING, F_SHADOWS, F_FOCAL_BLUR, F_POINT_LIGHT, F_SPECULAR = 1, 2, 4, 8, 16
+F_SINGLE_KERNEL = 1 << 8
+F_PER_LANE_SHADOWS = 1 << 9
 MODE_REF_TREE, MODE_BRUTE, MODE_BVH = 0, 1, 2
 TARGET_ROOT = 0x100
 

@@ -70,7 +70,8 @@ struct sr_scene {
     sr::Bvh     bvh;
     // device state
     DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris;
-    DBuf d_offsets, d_rowmap, d_pixels, d_stats, d_io[9];
+    DBuf d_offsets, d_rowmap, d_pixels, d_stats, d_io[9], d_hits, d_samples, d_counters;
+    int num_cus = 0;
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
     std::vector<double>  offsets_host;
     std::vector<int32_t> rowmap_host;
@@ -185,6 +186,12 @@ int prepare_frame(sr_scene* s, const sr_frame* f, sr::FrameConst& fc) {
     s->offsets_host.resize((size_t)fc.shadow_samples * 3);
     if (f->area_light_offsets) std::memcpy(s->offsets_host.data(), f->area_light_offsets, s->offsets_host.size() * sizeof(double));
     else sr::area_light_offsets(f->random_seed, fc.shadow_samples, s->offsets_host.data());
+    double r2max = 0;
+    for (int i = 0; i < fc.shadow_samples; ++i) {
+        const double* o = &s->offsets_host[3 * i];
+        r2max = std::max(r2max, o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
+    }
+    fc.light_radius = std::sqrt(r2max);
     return SR_OK;
 }
 
@@ -217,20 +224,62 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     SR_HIP(s->d_rowmap.reserve(std::max<size_t>(1, s->rowmap_host.size()) * sizeof(int32_t)));
     if (!s->rowmap_host.empty())
         SR_HIP(hipMemcpyAsync(s->d_rowmap.p, s->rowmap_host.data(), s->rowmap_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-    sr::RenderLaunch L{};
-    L.sc = dev_scene(s);
-    L.fc = fc;
-    L.mode = f->trace_mode;
-    L.offsets = (const double*)s->d_offsets.p;
-    L.row_map = (const int32_t*)s->d_rowmap.p;
-    L.pixels = d_pixels;
-    L.stats = d_stats;
-    L.stream = stream;
-    hipEvent_t e0, e1;
-    if ((rc = next_events(s, sr::K_RENDER, e0, e1))) return rc;
-    if (e0) SR_HIP(hipEventRecord(e0, stream));
-    SR_HIP(sr::launch_render(L));
-    if (e1) SR_HIP(hipEventRecord(e1, stream));
+    if (fc.num_rows == 0) return SR_OK;
+    if (f->flags & SR_F_SINGLE_KERNEL) {
+        sr::RenderLaunch L{};
+        L.sc = dev_scene(s);
+        L.fc = fc;
+        L.mode = f->trace_mode;
+        L.offsets = (const double*)s->d_offsets.p;
+        L.row_map = (const int32_t*)s->d_rowmap.p;
+        L.pixels = d_pixels;
+        L.stats = d_stats;
+        L.stream = stream;
+        hipEvent_t e0, e1;
+        if ((rc = next_events(s, sr::K_RENDER, e0, e1))) return rc;
+        if (e0) SR_HIP(hipEventRecord(e0, stream));
+        SR_HIP(sr::launch_render(L));
+        if (e1) SR_HIP(hipEventRecord(e1, stream));
+        return SR_OK;
+    }
+    // ---- default: the primary / shadow / resolve pipeline, in row bands ----
+    const long long n2 = (long long)fc.sub_pixel_res * fc.sub_pixel_res;
+    const long long kMaxBandSamples = 32ll << 20;                     // 32 Mi samples => 2 GiB hit queue at most
+    long long band_rows = std::max<long long>(16, (kMaxBandSamples / ((long long)fc.width * n2)) / 16 * 16);
+    band_rows = std::min<long long>(band_rows, ((long long)fc.num_rows + 15) / 16 * 16);
+    const long long band_samples = band_rows * fc.width * n2;
+    const bool shadows = (fc.flags & SR_F_SHADOWS) != 0;
+    if (shadows) SR_HIP(s->d_hits.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
+    if (n2 > 1) SR_HIP(s->d_samples.reserve((size_t)band_samples * 4));
+    SR_HIP(s->d_counters.reserve(64));
+    if (!s->num_cus) {
+        hipDeviceProp_t prop;
+        SR_HIP(hipGetDeviceProperties(&prop, s->device));
+        s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    sr::PipelineLaunch P{};
+    P.sc = dev_scene(s);
+    P.fc = fc;
+    P.mode = f->trace_mode;
+    P.offsets = (const double*)s->d_offsets.p;
+    P.row_map = (const int32_t*)s->d_rowmap.p;
+    P.pixels = d_pixels;
+    P.samples = (uint32_t*)s->d_samples.p;
+    P.hits = s->d_hits.p;
+    P.hit_count = (unsigned int*)s->d_counters.p;
+    P.work_head = P.hit_count + 1;
+    P.band_rows = (int32_t)band_rows;
+    P.persistent_blocks = s->num_cus * 8;
+    P.per_lane_shadows = (f->flags & SR_F_PER_LANE_SHADOWS) != 0;
+    P.stats = d_stats;
+    P.stream = stream;
+    P.user = s;
+    P.get_events = [](void* user, int kid, hipEvent_t* a, hipEvent_t* b) {
+        hipEvent_t x = nullptr, y = nullptr;
+        if (next_events((sr_scene*)user, kid, x, y) != SR_OK) { x = y = nullptr; }
+        *a = x; *b = y;
+    };
+    SR_HIP(sr::launch_pipeline(P));
     return SR_OK;
 }
 
@@ -263,7 +312,7 @@ void sr_destroy(sr_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris,
-                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_stats};
+                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters};
         for (DBuf* b : bufs) b->release();
         for (DBuf& b : s->d_io) b.release();
         for (int k = 0; k < sr::K_COUNT; ++k)

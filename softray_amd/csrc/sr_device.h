@@ -42,6 +42,29 @@ struct RenderLaunch {
 // The one-kernel renderer: ray generation, traversal, shading, inline shadow rays, sub-pixel resolve.
 hipError_t launch_render(const RenderLaunch& L);
 
+// The default path: k_primary -> k_shadow -> k_resolve (sr_pipeline.hip).
+struct PipelineLaunch {
+    DevScene    sc;
+    FrameConst  fc;
+    int32_t     mode;
+    const double*  offsets;     // device [shadow_samples][3]
+    const int32_t* row_map;     // device [num_rows]
+    uint32_t*   pixels;         // device output frame (full surface or compact strips)
+    uint32_t*   samples;        // device [band_rows * width * n^2] sample colours (sub_pixel_res > 1 only)
+    void*       hits;           // device hit queue, band_rows * width * n^2 records of pipeline_hit_record_bytes()
+    unsigned int* hit_count;    // device uint[2]: {hit_count, work_head}
+    unsigned int* work_head;    // = hit_count + 1
+    int32_t     band_rows;      // rows per band (multiple of 16)
+    int32_t     persistent_blocks;
+    bool        per_lane_shadows; // force k_shadow (one lane per hit) instead of k_shadow_packet (cross-check)
+    unsigned long long* stats;  // device [8] or nullptr
+    hipStream_t stream;
+    void (*get_events)(void* user, int kernel_id, hipEvent_t* start, hipEvent_t* stop);   // optional per-launch timing
+    void*       user;
+};
+hipError_t launch_pipeline(const PipelineLaunch& L);
+size_t pipeline_hit_record_bytes();
+
 struct TraceLaunch {
     DevScene sc;
     int32_t  mode;              // SR_MODE_*

@@ -1,0 +1,480 @@
+// sr_trace.h -- device-side ray/primitive/tree arithmetic shared by every kernel (device code only).
+// See sr_kernels.hip for the list of reference functions restated here.
+#pragma once
+#include "sr_device.h"
+
+#include <float.h>
+
+namespace sr {
+
+// --------------------------------------------------------------------------------------------------
+// FP64 3-vectors in the reference's operand order (Engine3D/Vector.cs)
+// --------------------------------------------------------------------------------------------------
+struct D3 {
+    double x, y, z;
+};
+__device__ __forceinline__ D3 mk(double x, double y, double z) { D3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ D3 operator+(D3 a, D3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ D3 operator-(D3 a, D3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ D3 operator*(D3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ D3 operator*(double s, D3 a) { return mk(s * a.x, s * a.y, s * a.z); }
+__device__ __forceinline__ D3 neg(D3 a) { return mk(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ double dot(D3 a, D3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ double length(D3 v) { return sqrt(v.x * v.x + v.y * v.y + v.z * v.z); }
+__device__ __forceinline__ D3 normalise(D3 v) {            // Vector.Normalise: multiply by 1/len
+    double inv = 1.0 / length(v);
+    return mk(v.x * inv, v.y * inv, v.z * inv);
+}
+__device__ __forceinline__ double comp(D3 v, int axis) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); }
+
+// C# unchecked (byte)(double): truncate toward zero, keep the low 8 bits; NaN / huge -> 0 (x64 cvttsd2si)
+__device__ __forceinline__ uint32_t to_byte(double d) {
+    if (!(d > -2147483649.0 && d < 2147483648.0)) return 0u;
+    return (uint32_t)((int32_t)d) & 0xffu;
+}
+// Color.ModulatePackedColor (Engine3D/Color.cs:124-133)
+__device__ __forceinline__ uint32_t modulate(uint32_t color, uint32_t amount) {
+    uint32_t r = (color >> 16) & 0xffu, g = (color >> 8) & 0xffu, b = color & 0xffu;
+    r = ((r * amount) >> 8) & 0xffu;
+    g = ((g * amount) >> 8) & 0xffu;
+    b = ((b * amount) >> 8) & 0xffu;
+    return (255u << 24) + (r << 16) + (g << 8) + b;
+}
+
+struct Hit {
+    double   t;
+    D3       pos, nrm;
+    uint32_t color;
+    int32_t  tri;
+};
+struct Ctr {
+    uint32_t geom, nodes, leaves, rays;
+};
+
+// --------------------------------------------------------------------------------------------------
+// primitives
+// --------------------------------------------------------------------------------------------------
+// Plane.IntersectRay on p[0..3] = {unit normal, originDist}
+__device__ __forceinline__ bool plane_hit(const double* p, D3 s, D3 d, double& t, D3& pos) {
+    double startDist = s.x * p[0] + s.y * p[1] + s.z * p[2];
+    double dirDist = d.x * p[0] + d.y * p[1] + d.z * p[2];
+    if (dirDist >= 0.0) return false;                      // one-sided
+    double rf = p[3] - startDist;
+    if (!(rf <= 0.0)) return false;
+    rf = rf / dirDist;
+    pos = s + d * rf;
+    t = rf;
+    return true;
+}
+// Triangle.IntersectRay on the 15-double record of sr_types.h
+__device__ __forceinline__ bool tri_hit(const double* p, D3 s, D3 d, double& t, D3& pos) {
+    double rf; D3 q;
+    if (!plane_hit(p, s, d, rf, q)) return false;
+    D3 w = mk(q.x - p[4], q.y - p[5], q.z - p[6]);
+    double sv = (w.x * p[7] + w.y * p[8] + w.z * p[9]) / p[10];
+    if (sv < 0.0 || sv > 1.0) return false;
+    double tv = (w.x * p[11] + w.y * p[12] + w.z * p[13]) / p[14];
+    if (sv >= 0.0 && tv >= 0.0 && sv + tv <= 1.0) { t = rf; pos = q; return true; }
+    return false;
+}
+// Sphere.IntersectRay on p[0..4] = {centre, radius, radiusSqr}; rayFrac is a DISTANCE (dir is normalised)
+__device__ __forceinline__ bool sphere_hit(const double* p, D3 s, D3 d, double& t, D3& pos, D3& nrm) {
+    d = normalise(d);
+    D3 oc = mk(s.x - p[0], s.y - p[1], s.z - p[2]);
+    double b = dot(oc, d);
+    if (b > p[3]) return false;
+    double distSqr = oc.x * oc.x + oc.y * oc.y + oc.z * oc.z;
+    double term = b * b - distSqr + p[4];
+    if (term < 1e-10) return false;
+    double q = sqrt(term);
+    double f1 = -b - q, f2 = -b + q;
+    double rf = (f1 >= 0 ? f1 : f2);
+    if (rf < 0) return false;
+    t = rf;
+    pos = s + d * rf;
+    nrm = normalise(mk(pos.x - p[0], pos.y - p[1], pos.z - p[2]));
+    return true;
+}
+
+// --------------------------------------------------------------------------------------------------
+// root-box clip (AxisAlignedBox.ContainsPoint / IntersectLineSegment / ClipLineSegment)
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool inside(const double* lo, const double* hi, D3 p) {
+    return lo[0] < p.x && p.x < hi[0] && lo[1] < p.y && p.y < hi[1] && lo[2] < p.z && p.z < hi[2];
+}
+// dot with the unit normal of box plane I (the literal 3-term product: x*0.0 is kept, it is not foldable)
+template <int I>
+__device__ __forceinline__ double plane_dot(D3 v) {
+    constexpr double nx = (I == 0) ? -1.0 : (I == 3 ? 1.0 : 0.0);
+    constexpr double ny = (I == 1) ? -1.0 : (I == 4 ? 1.0 : 0.0);
+    constexpr double nz = (I == 2) ? -1.0 : (I == 5 ? 1.0 : 0.0);
+    return v.x * nx + v.y * ny + v.z * nz;
+}
+template <int I>
+__device__ __forceinline__ void seg_plane(const RootBox& rb, D3 a, D3 b, double& closest, D3& cpos) {
+    double sd = plane_dot<I>(a), ed = plane_dot<I>(b);
+    double f = (rb.pd[I] - sd) / (ed - sd);                // Plane.IntersectLineSegment, Plane.cs:111-138
+    if (0.0 <= f && f <= 1.0) {
+        D3 p = a + (b - a) * f;
+        if (f < closest && inside(rb.lo, rb.hi, p)) { closest = f; cpos = p; }
+    }
+}
+__device__ __forceinline__ bool box_segment(const RootBox& rb, D3 a, D3 b, D3& out) {
+    double closest = DBL_MAX;
+    D3 cpos = mk(0, 0, 0);
+    seg_plane<0>(rb, a, b, closest, cpos);
+    seg_plane<1>(rb, a, b, closest, cpos);
+    seg_plane<2>(rb, a, b, closest, cpos);
+    seg_plane<3>(rb, a, b, closest, cpos);
+    seg_plane<4>(rb, a, b, closest, cpos);
+    seg_plane<5>(rb, a, b, closest, cpos);
+    if (closest == DBL_MAX) return false;
+    out = cpos;
+    return true;
+}
+__device__ __forceinline__ bool clip_segment(const RootBox& rb, D3& start, D3& end) {
+    bool si = inside(rb.lo, rb.hi, start), ei = inside(rb.lo, rb.hi, end);
+    if (si && ei) return true;
+    D3 ip;
+    if (!box_segment(rb, start, end, ip)) return false;
+    if (si) { end = ip; return true; }
+    D3 original = start;
+    start = ip;
+    if (!ei) {
+        if (box_segment(rb, end, original, ip)) end = ip;
+    }
+    return true;
+}
+
+// Per-lane traversal stack in LDS, laid out [level][thread]: consecutive lanes hit consecutive banks.
+struct Stack {
+    int32_t* base;      // &lds[threadIdx]
+    int32_t  stride;    // blockDim
+    __device__ __forceinline__ void put(int level, int32_t v) { base[level * stride] = v; }
+    __device__ __forceinline__ int32_t get(int level) const { return base[level * stride]; }
+};
+
+// --------------------------------------------------------------------------------------------------
+// SpatialSubdivision.IntersectRay -- literal traversal of the reference tree
+// --------------------------------------------------------------------------------------------------
+__device__ bool ref_tree_intersect(const DevScene& sc, const Rec128* tris, Stack st, D3 s, D3 d, Hit& out, Ctr& c) {
+    D3 end = s + d * 10000.0;
+    D3 original = s;
+    if (!clip_segment(sc.root, s, end)) return false;
+    double offset = length(original - s) / length(d);       // originalStart.Distance(start) / dir.Length
+
+    int sp = 0;
+    st.put(sp++, 0);
+    while (sp > 0) {
+        int32_t ni = st.get(--sp);
+        if (ni < 0) continue;                                // RecursiveRayTrace(null) -> null
+        c.nodes++;
+        const RefNode n = sc.rnodes[ni];
+        if (n.axis < 0) {                                    // leaf: GetClosestIntersection
+            c.leaves++;
+            const LeafBox* lb = &sc.rboxes[n.box];
+            double best = DBL_MAX;
+            int32_t bestTri = -1;
+            D3 bestPos = mk(0, 0, 0);
+            for (int k = 0; k < n.b; ++k) {
+                int32_t ti = sc.rleaf[n.a + k];
+                const Rec128* r = &tris[ti];
+                double t; D3 pos;
+                if (tri_hit(r->p, s, d, t, pos) && t < best) {
+                    if (inside(lb->lo, lb->hi, pos)) { best = t; bestTri = ti; bestPos = pos; }
+                }
+                c.geom++;
+            }
+            if (best < DBL_MAX) {
+                const Rec128* r = &tris[bestTri];
+                out.t = best + offset;
+                out.pos = bestPos;
+                out.nrm = mk(r->p[0], r->p[1], r->p[2]);
+                out.color = r->color;
+                out.tri = r->aux;
+                return true;
+            }
+            continue;
+        }
+        bool sN = comp(s, n.axis) >= n.split;                // Point.IntersectPlane, Point.cs:35-50
+        bool eN = comp(end, n.axis) >= n.split;
+        int32_t nearC = sN ? n.a : n.b, farC = sN ? n.b : n.a;
+        if (eN != sN) st.put(sp++, farC);
+        st.put(sp++, nearC);
+    }
+    return false;
+}
+
+// --------------------------------------------------------------------------------------------------
+// GeometryCollection over all model triangles (rayTraceSubdivision = false)
+// --------------------------------------------------------------------------------------------------
+template <bool ANY>
+__device__ bool brute_intersect(const Rec128* tris, int ntris, D3 s, D3 d, Hit& out, Ctr& c) {
+    double best = DBL_MAX;
+    int32_t bestK = -1;
+    D3 bestPos = mk(0, 0, 0);
+    for (int k = 0; k < ntris; ++k) {
+        double t; D3 pos;
+        c.geom++;
+        if (tri_hit(tris[k].p, s, d, t, pos) && t < best) {
+            best = t; bestK = k; bestPos = pos;
+            if (ANY && t <= 1.0) { out.t = t; out.tri = k; return true; }
+        }
+    }
+    if (bestK < 0) return false;
+    out.t = best;
+    out.pos = bestPos;
+    out.nrm = mk(tris[bestK].p[0], tris[bestK].p[1], tris[bestK].p[2]);
+    out.color = tris[bestK].color;
+    out.tri = tris[bestK].aux;
+    return true;
+}
+
+// --------------------------------------------------------------------------------------------------
+// Own BVH: fp32 conservative box culling, FP64 reference triangle arithmetic at the leaves.
+// Result = nearest hit (clipped start, hit inside the root box, ties -> lowest TriangleIndex); with ANY
+// it answers "is there a hit with rayFrac <= 1.0" (the only thing ShadowMethod.cs:170 asks).
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void slab(const float* lo, const float* hi, float ox, float oy, float oz,
+                                     float ix, float iy, float iz, float& tin, float& tout) {
+    float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
+    float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
+    float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
+    // fminf/fmaxf drop a NaN operand ((lo-o)==0 times inf): conservative
+    tin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    tout = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+}
+
+template <bool ANY>
+__device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out, Ctr& c) {
+    D3 end = s + d * 10000.0;
+    D3 original = s;
+    if (!clip_segment(sc.root, s, end)) return false;
+    double offset = length(original - s) / length(d);
+
+    const float ox = (float)(s.x - sc.root.centre[0]), oy = (float)(s.y - sc.root.centre[1]), oz = (float)(s.z - sc.root.centre[2]);
+    const float ix = 1.0f / (float)d.x, iy = 1.0f / (float)d.y, iz = 1.0f / (float)d.z;
+    const float kInfl = 1.0f + 9.5367431640625e-7f;          // 1 + 2^-20
+    float tlim = FLT_MAX;
+    if (ANY) {
+        // occluder <=> fl(t + offset) <= 1.0 ; nothing beyond t = 1 - offset (inflated) can qualify
+        double lim = 1.0 - offset;
+        if (lim < 0.0) return false;
+        tlim = (float)lim * kInfl + 1e-30f;
+    }
+    double best = DBL_MAX;
+    int32_t bestIdx = 0x7fffffff, bestK = -1;
+    D3 bestPos = mk(0, 0, 0);
+
+    int sp = 0;
+    int32_t ni = 0;
+    for (;;) {
+        const BvhNode n = sc.bnodes[ni];
+        c.nodes++;
+        float t0, x0, t1, x1;
+        slab(n.lo0, n.hi0, ox, oy, oz, ix, iy, iz, t0, x0);
+        slab(n.lo1, n.hi1, ox, oy, oz, ix, iy, iz, t1, x1);
+        bool h0 = n.n0 >= 0 && t0 <= x0 && x0 >= 0.0f && t0 <= tlim;
+        bool h1 = n.n1 >= 0 && t1 <= x1 && x1 >= 0.0f && t1 <= tlim;
+#pragma unroll
+        for (int side = 0; side < 2; ++side) {
+            bool h = side ? h1 : h0;
+            int32_t cn = side ? n.n1 : n.n0, cc = side ? n.c1 : n.c0;
+            if (h && cn > 0) {
+                c.leaves++;
+                for (int k = cc; k < cc + cn; ++k) {
+                    const Rec128* r = &sc.btris[k];
+                    double t; D3 pos;
+                    c.geom++;
+                    if (tri_hit(r->p, s, d, t, pos) && inside(sc.root.lo, sc.root.hi, pos)) {
+                        if (ANY) {
+                            if (t + offset <= 1.0) { out.t = t + offset; out.tri = k; return true; }   // out.tri = record position: the caller's blocker cache
+                        } else {
+                            int32_t idx = r->aux;
+                            if (t < best || (t == best && idx < bestIdx)) {
+                                best = t; bestIdx = idx; bestK = k; bestPos = pos;
+                                tlim = (float)best * kInfl + 1e-30f;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        bool i0 = h0 && n.n0 == 0 && t0 <= tlim, i1 = h1 && n.n1 == 0 && t1 <= tlim;
+        if (i0 && i1) {
+            bool first0 = t0 <= t1;
+            int32_t farC = first0 ? n.c1 : n.c0;
+            float farT = first0 ? t1 : t0;
+            st.put(sp++, farC);
+            st.put(sp++, __float_as_int(farT));
+            ni = first0 ? n.c0 : n.c1;
+        } else if (i0) {
+            ni = n.c0;
+        } else if (i1) {
+            ni = n.c1;
+        } else {
+            bool found = false;
+            while (sp > 0) {
+                float ft = __int_as_float(st.get(--sp));
+                int32_t cand = st.get(--sp);
+                if (ft <= tlim) { ni = cand; found = true; break; }
+            }
+            if (!found) break;
+        }
+    }
+    if (ANY || bestK < 0) return false;
+    const Rec128* r = &sc.btris[bestK];
+    out.t = best + offset;
+    out.pos = bestPos;
+    out.nrm = mk(r->p[0], r->p[1], r->p[2]);
+    out.color = r->color;
+    out.tri = r->aux;
+    return true;
+}
+
+// --------------------------------------------------------------------------------------------------
+// Blocker cache for any-hit (shadow) rays: "does THIS triangle record occlude the ray" with exactly the
+// predicate of the full traversal (same clip, same rayFrac offset, same root-box containment).  Any
+// triangle that satisfies it proves rayFrac <= 1.0 for the nearest hit, which is all ShadowMethod.cs:170
+// looks at -- so testing a recently found occluder first never changes a result.
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool bvh_cached_blocks(const DevScene& sc, int32_t k, D3 s, D3 d) {
+    D3 end = s + d * 10000.0;
+    D3 original = s;
+    if (!clip_segment(sc.root, s, end)) return false;
+    double offset = length(original - s) / length(d);
+    double t; D3 pos;
+    const Rec128* r = &sc.btris[k];
+    return tri_hit(r->p, s, d, t, pos) && inside(sc.root.lo, sc.root.hi, pos) && (t + offset <= 1.0);
+}
+__device__ __forceinline__ bool brute_cached_blocks(const Rec128* tris, int32_t k, D3 s, D3 d) {
+    double t; D3 pos;
+    return tri_hit(tris[k].p, s, d, t, pos) && (t <= 1.0);
+}
+
+// --------------------------------------------------------------------------------------------------
+// model + root geometry
+// --------------------------------------------------------------------------------------------------
+enum { MODE_REF = 0, MODE_BRUTE = 1, MODE_BVH = 2 };
+
+template <int MODE, bool ANY>
+__device__ __forceinline__ bool model_intersect(const DevScene& sc, const Rec128* tris, Stack st, D3 s, D3 d, Hit& out, Ctr& c) {
+    if (MODE == MODE_REF) return ref_tree_intersect(sc, tris, st, s, d, out, c);
+    if (MODE == MODE_BRUTE) return brute_intersect<ANY>(tris, sc.ntris, s, d, out, c);
+    return bvh_intersect<ANY>(sc, st, s, d, out, c);
+}
+
+// Root of the decorator chain (Renderer.cs:1536-1549): the model, or GeometryCollection[extra..., model].
+// With ANY the caller only needs "exists rayFrac <= 1.0" (<=> nearest.rayFrac <= 1.0).
+template <int MODE, bool ANY, bool EXTRA>
+__device__ bool root_intersect(const DevScene& sc, const Rec128* tris, const Rec128* extra, Stack st, D3 s, D3 d, Hit& out, Ctr& c) {
+    if (!EXTRA) return model_intersect<MODE, ANY>(sc, tris, st, s, d, out, c);
+    bool any = false;
+    double best = DBL_MAX;
+    for (int i = 0; i < sc.nextra; ++i) {
+        const Rec128* r = &extra[i];
+        double t; D3 pos, nrm;
+        bool ok;
+        int kind = r->aux;
+        if (kind == 0) ok = sphere_hit(r->p, s, d, t, pos, nrm);
+        else if (kind == 1) { ok = plane_hit(r->p, s, d, t, pos); nrm = mk(r->p[0], r->p[1], r->p[2]); }
+        else { ok = tri_hit(r->p, s, d, t, pos); nrm = mk(r->p[0], r->p[1], r->p[2]); }
+        c.geom++;
+        if (ok && t < best) {
+            best = t; any = true;
+            out.t = t; out.pos = pos; out.nrm = nrm; out.color = r->color; out.tri = -1;
+            if (ANY && t <= 1.0) return true;
+        }
+    }
+    Hit mh;
+    if (model_intersect<MODE, ANY>(sc, tris, st, s, d, mh, c) && mh.t < best) { out = mh; any = true; }
+    return any;
+}
+
+// --------------------------------------------------------------------------------------------------
+// shading (ShadingMethod.IntersectRay / CalcLighting)
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ D3 mul3x4(const double* m, D3 v) {      // Matrix.Multiply3X4, Matrix.cs:49-56
+    return mk(v.x * m[0] + v.y * m[1] + v.z * m[2] + m[3],
+              v.x * m[4] + v.y * m[5] + v.z * m[6] + m[7],
+              v.x * m[8] + v.y * m[9] + v.z * m[10] + m[11]);
+}
+__device__ __forceinline__ D3 mul3x3(const double* m, D3 v) {      // Instance.TransformDirection(Reverse)
+    return mk(v.x * m[0] + v.y * m[1] + v.z * m[2],
+              v.x * m[4] + v.y * m[5] + v.z * m[6],
+              v.x * m[8] + v.y * m[9] + v.z * m[10]);
+}
+__device__ uint32_t shade(const FrameConst& fc, D3 pos, D3 nrm, uint32_t color) {
+    D3 v = mul3x4(fc.t, pos);                                      // Instance.TransformPosToView, Instance.cs:168-184
+    v.x = v.x / v.z * fc.fov_depth;
+    v.y = v.y / v.z * fc.fov_depth;
+    v.z = (v.z - fc.position_z + 1.0) * 0.5;
+    D3 n = mul3x3(fc.t, nrm);
+    D3 L;
+    if (fc.flags & 8u) L = normalise(mk(fc.light_pos_view[0] - v.x, fc.light_pos_view[1] - v.y, fc.light_pos_view[2] - v.z));
+    else L = mk(-fc.light_dir_view[0], -fc.light_dir_view[1], -fc.light_dir_view[2]);
+    double diff = dot(L, n);
+    diff = (0.0 > diff) ? 0.0 : diff;                              // Math.Max(0.0, x)
+    double spec = 0.0;
+    if (fc.flags & 16u) {
+        D3 V = normalise(neg(v));
+        D3 R = 2.0 * dot(L, n) * n - L;
+        double ca = dot(R, V);
+        spec = pow(ca, fc.shininess);
+        spec = (0.0 > spec) ? 0.0 : spec;
+    }
+    double ch = 1.0 * fc.ambient + 1.0 * diff + 1.0 * spec;       // white materials, Color * double
+    ch = (ch < 1.0) ? ch : ((ch != ch) ? ch : 1.0);                // Math.Min(c, 1.0)
+    return modulate(color, to_byte(255 * ch));
+}
+
+// ShadowMethod.TraceRaysForSoftShadows: fraction of the area-light samples that reach the surface point
+template <int MODE, bool EXTRA>
+__device__ uint32_t soft_shadow(const DevScene& sc, const FrameConst& fc, const Rec128* tris, const Rec128* extra,
+                                const double* offsets, Stack st, D3 pos, D3 nrm, Ctr& c) {
+    int escapes = 0;
+    D3 shadowEnd = pos + nrm * 0.001;                              // shadowProbeOffset
+    for (int i = 0; i < fc.shadow_samples; ++i) {
+        D3 off = mk(offsets[3 * i], offsets[3 * i + 1], offsets[3 * i + 2]);
+        D3 rs, rd;
+        if (fc.flags & 8u) {
+            D3 src = mk(fc.light_pos_model[0] + off.x, fc.light_pos_model[1] + off.y, fc.light_pos_model[2] + off.z);
+            rd = shadowEnd - src;
+            rs = src;
+        } else {
+            rd = mk(fc.light_dir_model[0], fc.light_dir_model[1], fc.light_dir_model[2]);
+            rs = shadowEnd + rd * 1000.0 + off;
+        }
+        Hit h;
+        bool blocked;
+        c.rays++;
+        if (MODE == MODE_REF) {
+            // the reference tree returns ITS nearest hit; only that hit's rayFrac is compared with 1.0
+            blocked = root_intersect<MODE, false, EXTRA>(sc, tris, extra, st, rs, rd, h, c) && !(h.t > 1.0);
+        } else {
+            blocked = root_intersect<MODE, true, EXTRA>(sc, tris, extra, st, rs, rd, h, c) && !(h.t > 1.0);
+        }
+        if (!blocked) escapes++;
+    }
+    double frac = (double)escapes / (double)fc.shadow_samples;
+    return to_byte(frac * 255);
+}
+
+// TraceRayComplex with the decorator chain of one frame
+template <int MODE, bool EXTRA>
+__device__ uint32_t trace_camera_ray(const DevScene& sc, const FrameConst& fc, const Rec128* tris, const Rec128* extra,
+                                     const double* offsets, Stack st, D3 s, D3 d, Ctr& prim, Ctr& sec) {
+    Hit h;
+    if (!root_intersect<MODE, false, EXTRA>(sc, tris, extra, st, s, d, h, prim)) return fc.background;
+    uint32_t color = h.color;
+    if (fc.flags & 1u) color = shade(fc, h.pos, h.nrm, color);
+    if (fc.flags & 2u) color = modulate(color, soft_shadow<MODE, EXTRA>(sc, fc, tris, extra, offsets, st, h.pos, h.nrm, sec));
+    return color;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace sr

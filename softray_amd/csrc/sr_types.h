@@ -80,6 +80,7 @@ struct FrameConst {
     double   light_dir_model[3], light_pos_model[3];
     double   start_world[3];     // R^-1 * (0,0,-Position.z), Renderer.cs:1717
     double   aspect;             // (double)height / (double)width, Renderer.cs:621
+    double   light_radius;       // max |area-light offset| (0.2 for the reference table): bounds the shadow shaft
 };
 
 }  // namespace sr

@@ -13,11 +13,28 @@ pytestmark = pytest.mark.gpu
 NCPU = os.cpu_count() or 8
 
 
-def as_sr(frame, mode=None):
+def as_sr(frame, mode=None, single_kernel=False, per_lane=False):
     f = sa.Frame.from_buffer_copy(bytes(frame))
     if mode is not None:
         f.trace_mode = mode
+    if single_kernel:
+        f.flags |= sa._lib.F_SINGLE_KERNEL
+    if per_lane:
+        f.flags |= sa._lib.F_PER_LANE_SHADOWS
     return f
+
+
+def render_both(g, frame, mode=None):
+    """The default path (k_primary -> k_shadow_packet / k_shadow -> k_resolve), the per-lane shadow kernel and the
+    one-kernel renderer are three independent schedules of the same arithmetic: they must agree bit for bit."""
+    a, sa_ = g.render(as_sr(frame, mode))
+    b, sb_ = g.render(as_sr(frame, mode, single_kernel=True))
+    assert np.array_equal(a, b), "pipeline and single-kernel renderer differ"
+    assert np.array_equal(sa_, sb_)
+    if frame.flags & sa.F_SHADOWS:
+        c, _ = g.render(as_sr(frame, mode, per_lane=True))
+        assert np.array_equal(a, c), "k_shadow_packet and k_shadow differ"
+    return a, sa_
 
 
 @pytest.fixture(scope="module")
@@ -36,7 +53,7 @@ def obj_pair():
 def test_goldens_on_gpu(obj_pair, name, res, kw):
     g, o = obj_pair
     f = make_frame(res, **kw)
-    got, gstats = g.render(as_sr(f))
+    got, gstats = render_both(g, f)
     want, ostats = o.render(f, threads=NCPU)
     assert int(np.count_nonzero((got.reshape(res, res) & 0xFFFFFF) != golden_rgb(name, res))) == 0
     assert np.array_equal(got, want)
@@ -50,7 +67,7 @@ def test_goldens_on_gpu(obj_pair, name, res, kw):
 def test_modes_match_oracle(obj_pair, mode, omode, kw):
     g, o = obj_pair
     f = make_frame(96, 64, mode=omode, **kw)
-    got, _ = g.render(as_sr(f, mode))
+    got, _ = render_both(g, f, mode)
     want, _ = o.render(f, threads=NCPU)
     assert np.array_equal(got, want)
     ref, _ = o.render(make_frame(96, 64, **kw), threads=NCPU)
@@ -122,7 +139,7 @@ def test_spheres_planes_triangles_extra_geometry():
         f = make_frame(res, depth=3.0, **kw)
         want, _ = o.render(f, threads=NCPU)
         for mode in (sa.MODE_REF_TREE, sa.MODE_BRUTE, sa.MODE_BVH):
-            got, _ = g.render(as_sr(f, mode))
+            got, _ = render_both(g, f, mode)
             assert np.array_equal(got, want), (kw, mode)
     # ray batches through the root GeometryCollection (sphere rayFrac is a distance: Sphere.cs:164)
     rnd = orc.Random(99)
@@ -145,9 +162,9 @@ def test_random_scene_all_modes_vs_oracle_tree():
     assert g.tree_stats() == o.tree_stats()
     f = make_frame(128, depth=1.5, shadows=True)
     want, ostats = o.render(f, threads=NCPU)
-    got, gstats = g.render(as_sr(f, sa.MODE_REF_TREE))
+    got, gstats = render_both(g, f, sa.MODE_REF_TREE)
     assert np.array_equal(got, want) and np.array_equal(gstats, ostats)
-    got_bvh, _ = g.render(as_sr(f, sa.MODE_BVH))
+    got_bvh, _ = render_both(g, f, sa.MODE_BVH)
     assert np.array_equal(got_bvh, want)
     assert len(np.unique(want)) > 1000
 
