@@ -30,6 +30,7 @@ import torch.distributed as dist
 
 import softray_amd as sa
 from softray_amd import renderer as R
+from softray_amd.distributed import StripGather
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 S_NODE, S_TRI, S_PIX = 64, 128, 4   # bytes: BVH node (two fp32 child boxes + links), triangle record, pixel store
@@ -141,27 +142,16 @@ def main():
     strips = (args.strip_rows, world, rank) if world > 1 else None
     frame = make_frame(args, strips)
     npix = g.pixel_count(frame)
-    local = torch.empty(npix, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
-    full = None
-    gather_list = None
-    if world > 1:
-        counts = [sa.GpuScene.pixel_count(make_frame(args, (args.strip_rows, world, r))) for r in range(world)]
-        maxc = max(counts)
-        local = torch.empty(maxc, dtype=torch.int32, device=dev)      # padded so that every rank sends the same size
-        if rank == 0:
-            gather_list = [torch.empty(maxc, dtype=torch.int32, device=dev) for _ in range(world)]
-            full = torch.empty((args.res, args.res), dtype=torch.int32, device=dev)
-            row_idx = [torch.tensor([r for r in range(args.res) if (r // args.strip_rows) % world == k], device=dev)
-                       for k in range(world)]
+    sg = StripGather(args.res, args.res, args.strip_rows, world, rank, dev) if world > 1 else None
+    local = sg.local if sg else torch.empty(npix, dtype=torch.int32, device=dev)
+    if sg:
+        assert sg.counts[rank] == npix
 
     def step():
         g.render_device(frame, local.data_ptr(), stream.cuda_stream)
-        if world > 1:
-            dist.gather(local, gather_list, dst=0)                    # RCCL over xGMI: the one exchange step
-            if rank == 0:
-                for k in range(world):
-                    full[row_idx[k]] = gather_list[k][: counts[k]].view(-1, args.res)
+        if sg:
+            sg.exchange()                                             # RCCL gather over xGMI + de-interleave on rank 0
 
     for _ in range(args.warmup):
         step()

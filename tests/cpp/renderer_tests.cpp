@@ -1,0 +1,100 @@
+// renderer_tests.cpp -- the reference's golden-image tests (Engine3D-Tests/Raytrace/RendererTests.cs) driven through
+// the C++ host mirror softray_amd/host/Engine3D.hpp, i.e. through the same API a C# caller uses.
+// usage: renderer_tests <golden-dir>      exit 0 = every scenario has 0 differing RGB pixels
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "../../softray_amd/host/Engine3D.hpp"
+
+using namespace Engine3D;
+
+static const double kPi = 3.14159265358979323846;
+static std::vector<int32_t> pixels(400 * 400);              // RendererTests.cs:58 (one shared buffer)
+
+static bool ReadBmpRgb(const std::string& path, int& w, int& h, std::vector<uint32_t>& rgb) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::vector<unsigned char> d((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    if (d.size() < 54 || d[0] != 'B' || d[1] != 'M') return false;
+    uint32_t off; int32_t ww, hh; uint16_t bpp;
+    std::memcpy(&off, &d[10], 4); std::memcpy(&ww, &d[18], 4); std::memcpy(&hh, &d[22], 4); std::memcpy(&bpp, &d[28], 2);
+    if (bpp != 32 || hh <= 0) return false;
+    w = ww; h = hh; rgb.resize((size_t)w * h);
+    for (int y = 0; y < h; ++y)                              // bottom-up rows
+        for (int x = 0; x < w; ++x) {
+            uint32_t px; std::memcpy(&px, &d[off + 4 * ((size_t)(h - 1 - y) * w + x)], 4);
+            rgb[(size_t)y * w + x] = px & 0x00FFFFFFu;       // Format32bppRgb: alpha not compared
+        }
+    return true;
+}
+
+// RendererTests.RendererSetup (RendererTests.cs:65-90)
+static void RendererSetup(Renderer& renderer, const std::string& modelFileName, double pitchDegrees, double yawDegrees,
+                          double rollDegrees, double objectDepth, int resolution) {
+    renderer.BackgroundColor(0xff00ff);
+    renderer.SetRenderingSurface(resolution, resolution, pixels.data());
+    std::ifstream stream(modelFileName, std::ios::binary);
+    if (!stream) throw std::runtime_error("cannot open " + modelFileName);
+    renderer.Load3dsModelFromStream(stream);
+    auto inst = std::make_shared<Instance>(renderer.Model());
+    inst->Position = Vector(0.0, 0.0, objectDepth);
+    inst->Yaw = yawDegrees / 180.0 * kPi;
+    inst->Pitch = pitchDegrees / 180.0 * kPi;
+    inst->Roll = rollDegrees / 180.0 * kPi;
+    renderer.Instances.push_back(inst);
+}
+
+// RendererTests.RaytraceScenario (RendererTests.cs:381-459), in-scope flags only
+static int RaytraceScenario(const std::string& dir, bool shading, bool focalBlur, bool shadows, int subPixelRes, int resolution) {
+    const double objectDepth = 1.0;
+    Renderer renderer(0);
+    RendererSetup(renderer, dir + "/obj.3ds", -22.0, 135.0, 0.0, objectDepth, resolution);
+    renderer.rayTrace = true;
+    renderer.rayTraceSubdivision = true;
+    renderer.rayTraceShading = shading;
+    renderer.rayTraceFocalBlur = focalBlur;
+    renderer.rayTraceFocalDepth = objectDepth + 0.5;
+    renderer.rayTraceSubPixelRes = subPixelRes;
+    renderer.rayTraceShadows = shadows;
+    std::string name = std::string(shading ? "shading" : "noShading") + (shadows ? "_shadows" : "") + (focalBlur ? "_focalBlur" : "") +
+                       (focalBlur ? "x" + std::to_string(subPixelRes) : (subPixelRes > 1 ? "_" + std::to_string(subPixelRes) + "xAA" : ""));
+    std::string path = dir + "/raytrace/" + std::to_string(resolution) + "x" + std::to_string(resolution) + "/" + name + ".bmp";
+    renderer.Render();
+    int w, h; std::vector<uint32_t> base;
+    if (!ReadBmpRgb(path, w, h, base) || w != resolution || h != resolution) { std::printf("%-40s MISSING BASELINE\n", name.c_str()); return 1; }
+    int diff = 0;
+    for (int i = 0; i < w * h; ++i) if (((uint32_t)pixels[i] & 0x00FFFFFFu) != base[i]) ++diff;
+    std::printf("%-36s %3dx%-3d diff=%d rays=%lld nodeVisits=%lld\n", name.c_str(), w, h, diff, (long long)renderer.NumRaysFired(),
+                (long long)renderer.NumNodeVisits());
+    return diff == 0 ? 0 : 1;
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: %s <golden-dir>\n", argv[0]); return 2; }
+    std::string dir = argv[1];
+    try {
+        int bad = 0;
+        bad += RaytraceScenario(dir, true, false, false, 1, 100);       // shading
+        bad += RaytraceScenario(dir, false, false, false, 1, 100);      // noShading
+        bad += RaytraceScenario(dir, true, false, false, 2, 100);       // RaytraceAntialised (RendererTests.cs:140-149)
+        bad += RaytraceScenario(dir, true, false, false, 4, 100);
+        bad += RaytraceScenario(dir, true, false, false, 8, 100);
+        bad += RaytraceScenario(dir, true, false, true, 1, 100);        // RaytraceDynamicShadow (:154-160)
+        bad += RaytraceScenario(dir, true, true, true, 4, 50);          // RaytraceShadowAndFocalBlur (:179-188)
+        bad += RaytraceScenario(dir, true, false, true, 4, 50);         // RaytraceShadowAndAntiAlias (:207-213)
+        bad += RaytraceScenario(dir, true, true, false, 2, 100);
+        // error behaviour: Render() without a model draws nothing (Renderer.cs:736-739)
+        { Renderer r(0); r.rayTrace = true; r.SetRenderingSurface(4, 4, pixels.data()); r.Render(); }
+        // FormatException for a non-3DS stream (ThreeDSFile.cs:166-169)
+        try { Renderer r(0); std::ifstream s(dir + "/raytrace/100x100/shading.bmp", std::ios::binary); r.Load3dsModelFromStream(s); ++bad; std::printf("expected FormatException\n"); }
+        catch (const FormatException&) { std::printf("FormatException ok\n"); }
+        std::printf(bad ? "FAILED (%d)\n" : "ALL OK\n", bad);
+        return bad ? 1 : 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "exception: %s\n", e.what());
+        return 3;
+    }
+}
