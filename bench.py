@@ -223,7 +223,8 @@ def main():
                          "note": "algorithmic bytes = 4 B/pixel + 64 B/BVH node visit + 128 B/triangle test over all primary+shadow "
                                  "rays of one launch (ray counters from the device); a 128 MB scene lives in the 256 MB Infinity "
                                  "Cache, so this kernel is latency/issue-bound rather than HBM-bound"},
-            "kernels_ms": {k: v[0] for k, v in kt.items()},
+            "kernels_ms": {k: v[0] for k, v in kt.items()}, "kernel_launches": {k: v[1] for k, v in kt.items()},
+            "pipeline_counters_last_band": g.debug_counters(),
             "build_s": build_s, "d2h_ms": d2h_ms,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -201,6 +201,11 @@ int  sr_last_ray_stats(const sr_scene*, uint64_t out[8]);
 void sr_make_random_triangles(int32_t seed, int64_t n, double space, double extent, double origin, int32_t opaque,
                               double* v9, uint32_t* argb);
 
+/* Diagnostics only: the pipeline's device counters after the last row band of the last frame
+ * {hit points queued, per-lane shadow work head, hit points that needed the long (round-2) candidate list,
+ *  hit points sent to the exact per-lane fallback, fallback work head, 0, 0, 0}. */
+int  sr_debug_counters(sr_scene*, uint32_t out[8]);
+
 const char* sr_last_error(void);
 int32_t     sr_abi_version(void);
 

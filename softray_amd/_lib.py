@@ -25,7 +25,7 @@ SYMBOLS = [
     "sr_create", "sr_destroy", "sr_set_triangles", "sr_set_extra_geometry", "sr_build", "sr_tree_stats",
     "sr_render", "sr_render_device", "sr_frame_pixel_count", "sr_trace_rays", "sr_instance_matrices",
     "sr_default_fov_depth", "sr_area_light_offsets", "sr_load_3ds", "sr_num_triangles", "sr_get_triangles",
-    "sr_reset_kernel_times", "sr_kernel_times", "sr_last_ray_stats", "sr_make_random_triangles", "sr_last_error", "sr_abi_version",
+    "sr_reset_kernel_times", "sr_kernel_times", "sr_last_ray_stats", "sr_make_random_triangles", "sr_debug_counters", "sr_last_error", "sr_abi_version",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
     L.sr_last_ray_stats.restype = i32; L.sr_last_ray_stats.argtypes = [vp, vp]
     L.sr_make_random_triangles.restype = None
     L.sr_make_random_triangles.argtypes = [i32, i64, dbl, dbl, dbl, i32, vp, vp]
+    L.sr_debug_counters.restype = i32; L.sr_debug_counters.argtypes = [vp, vp]
     L.sr_last_error.restype = C.c_char_p; L.sr_last_error.argtypes = []
     L.sr_abi_version.restype = i32; L.sr_abi_version.argtypes = []
     _lib = L

@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -69,8 +70,8 @@ struct sr_scene {
     sr::RefTree ref;
     sr::Bvh     bvh;
     // device state
-    DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris;
-    DBuf d_offsets, d_rowmap, d_pixels, d_stats, d_io[9], d_hits, d_samples, d_counters;
+    DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab;
+    DBuf d_offsets, d_rowmap, d_pixels, d_stats, d_io[9], d_hits, d_samples, d_counters, d_cand_count, d_cand, d_fallback, d_r2list, d_r2state, d_cand_count2, d_cand2;
     int num_cus = 0;
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
     std::vector<double>  offsets_host;
@@ -103,6 +104,12 @@ int sync_geometry(sr_scene* s, uint32_t need_mode) {
         std::vector<sr::Rec128> ordered(s->bvh.order.size());
         for (size_t i = 0; i < ordered.size(); ++i) ordered[i] = s->tri_recs[s->bvh.order[i]];
         SR_HIP(s->d_btris.upload(ordered));
+        std::vector<sr::TriSlab> slabs(s->bvh.order.size());
+        for (size_t i = 0; i < slabs.size(); ++i) {
+            const double* p = &s->v9[(size_t)s->bvh.order[i] * 9];
+            slabs[i] = sr::make_tri_slab({p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}, s->root.centre);
+        }
+        SR_HIP(s->d_bslab.upload(slabs));
         s->bvh_dirty = false;
     }
     return SR_OK;
@@ -115,6 +122,7 @@ sr::DevScene dev_scene(const sr_scene* s) {
     d.rnodes = (const sr::RefNode*)s->d_rnodes.p; d.rboxes = (const sr::LeafBox*)s->d_rboxes.p; d.rleaf = (const int32_t*)s->d_rleaf.p;
     d.rdepth = s->ref.tree_depth;
     d.bnodes = (const sr::BvhNode*)s->d_bnodes.p; d.btris = (const sr::Rec128*)s->d_btris.p; d.bdepth = s->bvh.depth;
+    d.bslab = (const sr::TriSlab*)s->d_bslab.p;
     d.root = s->root;
     return d;
 }
@@ -192,6 +200,7 @@ int prepare_frame(sr_scene* s, const sr_frame* f, sr::FrameConst& fc) {
         r2max = std::max(r2max, o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
     }
     fc.light_radius = std::sqrt(r2max);
+    { const char* dbg = std::getenv("SR_DEBUG"); fc.debug = dbg ? std::atoi(dbg) : 0; }
     return SR_OK;
 }
 
@@ -244,12 +253,26 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     }
     // ---- default: the primary / shadow / resolve pipeline, in row bands ----
     const long long n2 = (long long)fc.sub_pixel_res * fc.sub_pixel_res;
-    const long long kMaxBandSamples = 32ll << 20;                     // 32 Mi samples => 2 GiB hit queue at most
+    const bool shadows = (fc.flags & SR_F_SHADOWS) != 0;
+    const bool shaft = shadows && f->trace_mode == SR_MODE_BVH && (fc.flags & SR_F_POINT_LIGHT) && fc.shadow_samples <= 128 &&
+                       !(f->flags & SR_F_PER_LANE_SHADOWS);
+    // samples per band: bounds the hit queue (64 B/sample) and, on the shaft path, the candidate lists (200 B/sample)
+    const long long kMaxBandSamples = shaft ? (8ll << 20) : (32ll << 20);
     long long band_rows = std::max<long long>(16, (kMaxBandSamples / ((long long)fc.width * n2)) / 16 * 16);
     band_rows = std::min<long long>(band_rows, ((long long)fc.num_rows + 15) / 16 * 16);
     const long long band_samples = band_rows * fc.width * n2;
-    const bool shadows = (fc.flags & SR_F_SHADOWS) != 0;
+    unsigned round2_cap = 0;
     if (shadows) SR_HIP(s->d_hits.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
+    if (shaft) {
+        SR_HIP(s->d_cand_count.reserve((size_t)band_samples * 4));
+        SR_HIP(s->d_cand.reserve((size_t)band_samples * sr::pipeline_shaft_cap() * 4));
+        SR_HIP(s->d_fallback.reserve((size_t)band_samples * 4));
+        round2_cap = (unsigned)std::max<long long>(1024, band_samples / 8);
+        SR_HIP(s->d_r2list.reserve((size_t)round2_cap * 4));
+        SR_HIP(s->d_r2state.reserve((size_t)round2_cap * sr::pipeline_round_state_bytes()));
+        SR_HIP(s->d_cand_count2.reserve((size_t)round2_cap * 4));
+        SR_HIP(s->d_cand2.reserve((size_t)round2_cap * sr::pipeline_shaft_cap2() * 4));
+    }
     if (n2 > 1) SR_HIP(s->d_samples.reserve((size_t)band_samples * 4));
     SR_HIP(s->d_counters.reserve(64));
     if (!s->num_cus) {
@@ -266,8 +289,15 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     P.pixels = d_pixels;
     P.samples = (uint32_t*)s->d_samples.p;
     P.hits = s->d_hits.p;
-    P.hit_count = (unsigned int*)s->d_counters.p;
-    P.work_head = P.hit_count + 1;
+    P.counters = (unsigned int*)s->d_counters.p;
+    P.cand_count = shaft ? (unsigned int*)s->d_cand_count.p : nullptr;
+    P.cand = shaft ? (int32_t*)s->d_cand.p : nullptr;
+    P.fallback = shaft ? (unsigned int*)s->d_fallback.p : nullptr;
+    P.round2_cap = round2_cap;
+    P.round2_list = (unsigned int*)s->d_r2list.p;
+    P.round2_state = s->d_r2state.p;
+    P.cand_count2 = (unsigned int*)s->d_cand_count2.p;
+    P.cand2 = (int32_t*)s->d_cand2.p;
     P.band_rows = (int32_t)band_rows;
     P.persistent_blocks = s->num_cus * 8;
     P.per_lane_shadows = (f->flags & SR_F_PER_LANE_SHADOWS) != 0;
@@ -311,8 +341,8 @@ int sr_create(int32_t device, sr_scene** out) {
 void sr_destroy(sr_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
-        DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris,
-                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters};
+        DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
+                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_cand_count, &s->d_cand, &s->d_fallback, &s->d_r2list, &s->d_r2state, &s->d_cand_count2, &s->d_cand2};
         for (DBuf* b : bufs) b->release();
         for (DBuf& b : s->d_io) b.release();
         for (int k = 0; k < sr::K_COUNT; ++k)
@@ -521,6 +551,18 @@ void sr_make_random_triangles(int32_t seed, int64_t n, double space, double exte
         uint32_t c = (uint32_t)rnd.next();                                              // (uint)random.Next()
         argb[i] = opaque ? (0xFF000000u | (c & 0xFFFFFFu)) : c;
     }
+}
+
+int sr_debug_counters(sr_scene* s, uint32_t out[8]) {
+    /* diagnostics: the pipeline's device counters after the last band of the last frame:
+       hit_count, k_shadow work head, fallback_count, fallback work head */
+    if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
+    int rc = use_device(s);
+    if (rc) return rc;
+    if (!s->d_counters.p) { for (int i = 0; i < 8; ++i) out[i] = 0; return SR_OK; }
+    SR_HIP(hipDeviceSynchronize());
+    SR_HIP(hipMemcpy(out, s->d_counters.p, 32, hipMemcpyDeviceToHost));
+    return SR_OK;
 }
 
 void sr_reset_kernel_times(sr_scene* s) {

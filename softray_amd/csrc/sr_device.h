@@ -21,11 +21,12 @@ struct DevScene {
     // own BVH
     const BvhNode* bnodes;
     const Rec128*  btris;       // triangle records gathered in leaf order (aux = TriangleIndex)
+    const TriSlab* bslab;       // fp32 shaft-prefilter records, same order as btris
     int32_t        bdepth;
     RootBox        root;
 };
 
-enum KernelId { K_RENDER = 0, K_TRACE = 1, K_PRIMARY = 2, K_SHADOW = 3, K_RESOLVE = 4, K_COUNT = 5 };
+enum KernelId { K_RENDER = 0, K_TRACE = 1, K_PRIMARY = 2, K_SHADOW = 3, K_RESOLVE = 4, K_SHAFT = 5, K_FALLBACK = 6, K_COUNT = 7 };
 const char* kernel_name(int id);
 
 struct RenderLaunch {
@@ -52,8 +53,15 @@ struct PipelineLaunch {
     uint32_t*   pixels;         // device output frame (full surface or compact strips)
     uint32_t*   samples;        // device [band_rows * width * n^2] sample colours (sub_pixel_res > 1 only)
     void*       hits;           // device hit queue, band_rows * width * n^2 records of pipeline_hit_record_bytes()
-    unsigned int* hit_count;    // device uint[2]: {hit_count, work_head}
-    unsigned int* work_head;    // = hit_count + 1
+    unsigned int* counters;     // device uint[8]: hits, k_shadow head, round-2 count, fallback count, fallback head
+    unsigned int* cand_count;   // device [band samples]: shaft candidate-list length | truncated flag (nullptr: no shaft path)
+    int32_t*    cand;           // device [band samples][pipeline_shaft_cap()]
+    unsigned int* fallback;     // device [band samples]: hits that need the exact per-lane fallback
+    unsigned int  round2_cap;   // capacity (hits) of the round-2 buffers below
+    unsigned int* round2_list;  // device [round2_cap] hit indices
+    void*         round2_state; // device [round2_cap] RoundState
+    unsigned int* cand_count2;  // device [round2_cap]
+    int32_t*      cand2;        // device [round2_cap][pipeline_shaft_cap2()]
     int32_t     band_rows;      // rows per band (multiple of 16)
     int32_t     persistent_blocks;
     bool        per_lane_shadows; // force k_shadow (one lane per hit) instead of k_shadow_packet (cross-check)
@@ -64,6 +72,10 @@ struct PipelineLaunch {
 };
 hipError_t launch_pipeline(const PipelineLaunch& L);
 size_t pipeline_hit_record_bytes();
+size_t pipeline_shaft_bytes_per_hit();
+int pipeline_shaft_cap();
+int pipeline_shaft_cap2();
+size_t pipeline_round_state_bytes();
 
 struct TraceLaunch {
     DevScene sc;

@@ -104,6 +104,40 @@ Rec128 make_plane_record(Vec3 point, Vec3 normal, uint32_t color) {
     r.aux = 1;
     return r;
 }
+TriSlab make_tri_slab(Vec3 v1, Vec3 v2, Vec3 v3, const double centre[3]) {
+    TriSlab t;
+    std::memset(&t, 0, sizeof(t));
+    const Vec3 c = {centre[0], centre[1], centre[2]};
+    const Vec3 a = sub(v1, c), b = sub(v2, c), d3 = sub(v3, c);
+    // the reference replaces a "zero" normal by (1,0,0) (Triangle.cs:42-43) and then accepts hits in the plane x = v1.x
+    // that need not be near the geometric triangle: such triangles get no planes (always candidates)
+    if (is_zero_vector(cross(sub(v2, v1), sub(v3, v1)))) return t;
+    Vec3 n = cross(sub(b, a), sub(d3, a));
+    double nl = std::sqrt(dot(n, n));
+    double e1 = std::sqrt(dot(sub(b, a), sub(b, a))), e2 = std::sqrt(dot(sub(d3, b), sub(d3, b))), e3 = std::sqrt(dot(sub(a, d3), sub(a, d3)));
+    double emax = std::max(e1, std::max(e2, e3));
+    // degenerate / needle-thin triangles: no usable planes -> all zeros = "always a candidate"
+    if (!(nl > 1e-12 * emax * emax) || !(emax > 0) || !std::isfinite(nl)) return t;
+    n = scale(n, 1.0 / nl);
+    const Vec3 P[3] = {a, b, d3};
+    float* mm[3] = {t.m1, t.m2, t.m3};
+    float* cc[3] = {&t.c1, &t.c2, &t.c3};
+    for (int k = 0; k < 3; ++k) {
+        const Vec3 p0 = P[k], p1 = P[(k + 1) % 3], p2 = P[(k + 2) % 3];
+        Vec3 e = sub(p1, p0);
+        Vec3 m = cross(n, e);                          // in-plane, perpendicular to the edge
+        double ml = std::sqrt(dot(m, m));
+        if (!(ml > 0)) { std::memset(&t, 0, sizeof(t)); return t; }
+        m = scale(m, 1.0 / ml);
+        if (dot(m, sub(p2, p0)) < 0) m = scale(m, -1.0);   // point towards the third vertex
+        mm[k][0] = (float)m.x; mm[k][1] = (float)m.y; mm[k][2] = (float)m.z;
+        *cc[k] = (float)dot(m, p0);
+    }
+    t.n[0] = (float)n.x; t.n[1] = (float)n.y; t.n[2] = (float)n.z;
+    t.d = (float)dot(n, a);
+    return t;
+}
+
 RootBox make_root_box(const double bmin[3], const double bmax[3]) {
     RootBox b;
     const double eps = 1e-10;

@@ -157,6 +157,8 @@ const char* kernel_name(int id) {
         case K_PRIMARY: return "k_primary";
         case K_SHADOW: return "k_shadow";
         case K_RESOLVE: return "k_resolve";
+        case K_SHAFT: return "k_shaft";
+        case K_FALLBACK: return "k_shadow_fallback";
         default: return "?";
     }
 }

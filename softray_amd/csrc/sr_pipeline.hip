@@ -140,8 +140,8 @@ __device__ __forceinline__ bool sample_blocked(const DevScene& sc, const FrameCo
 template <int MODE, bool EXTRA, bool STATS>
 __global__ __launch_bounds__(256) void k_shadow(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
                                                 const HitRec* __restrict__ hits, const unsigned int* __restrict__ hit_count,
-                                                unsigned int* __restrict__ work_head, uint32_t* __restrict__ samples,
-                                                int stack_levels, unsigned long long* stats) {
+                                                unsigned int* __restrict__ work_head, const unsigned int* __restrict__ index_list,
+                                                uint32_t* __restrict__ samples, int stack_levels, unsigned long long* stats) {
     const int tid = threadIdx.x, lane = tid & 63;
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
     // the area-light offset table staged in LDS behind the stacks (ShadowMethod.cs:63-73: 100 x 3 doubles)
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void k_shadow(DevScene sc, FrameConst fc, cons
             if (need) {
                 const unsigned int idx = base + (unsigned int)__popcll(m & lanemask_lt());
                 if (idx < total) {
-                    const HitRec r = hits[idx];
+                    const HitRec r = hits[index_list ? index_list[idx] : idx];
                     D3 pos = mk(r.pos[0], r.pos[1], r.pos[2]), nrm = mk(r.nrm[0], r.nrm[1], r.nrm[2]);
                     shadowEnd = pos + nrm * 0.001;                       // shadowProbeOffset, ShadowMethod.cs:10,151
                     sample = r.sample;
@@ -232,17 +232,24 @@ __global__ __launch_bounds__(256) void k_shadow(DevScene sc, FrameConst fc, cons
 }
 
 // --------------------------------------------------------------------------------------------------
-// k_shadow_packet (own BVH + point light): one WAVEFRONT per queued hit, lanes = area-light samples.
+// Shaft shadows (own BVH + point light): k_shaft + k_shadow_test.
 //
 // All S sample rays of one surface point end in the same point E' and start on a sphere of radius R
 // around the light: P_i(t) = C(t) + (1 - t) * off_i with the centre ray C(t) = (1-t) L + t E'.  A
-// triangle can be hit by ANY of them at parameter t only if its box is within (1-t) R of C(t).  So the
-// wave walks the BVH ONCE with that shaft (fp32, conservative, children nearest to E' first), gathers
-// the triangles of the leaves it touches in chunks, and every lane tests its own sample rays against a
-// chunk with the reference's exact FP64 arithmetic.  Samples that are blocked drop out; when none is
-// left the hit is finished early (fully shadowed points: a handful of nodes); when the shaft is
-// exhausted the remaining samples have provably no occluder (ShadowMethod.cs:170: nearest hit > 1.0 or
-// none).  No per-sample traversal at all; the result is exactly that of S independent any-hit searches.
+// triangle can be hit by ANY of them at parameter t only if its box is within (1-t) R of C(t).
+//
+//   k_shaft        lane = hit point.  Walks the BVH ONCE with that shaft (fp32, conservative, children
+//                  nearest to E' first) and writes the leaves it touches -- (first record, count) packed in
+//                  one int -- to the hit's candidate list in HBM, at most kShaftCap leaves (then the list is
+//                  flagged "truncated").  64 independent walks per wave hide the node-fetch latency.
+//   k_shadow_test  wave = hit point, lanes = area-light samples.  Stages the candidates' 128-byte records
+//                  through LDS (8 leaves = up to 32 records per pass, 16 B per lane, coalesced) and every
+//                  lane tests its own 1-2 sample rays against them with the reference's exact FP64
+//                  arithmetic.  Blocked samples drop out; when none is left the hit is finished.  If a
+//                  list is exhausted the remaining samples have provably no occluder (ShadowMethod.cs:170).
+//                  Only "truncated list AND a sample still undecided" goes to the fallback queue, which
+//                  k_shadow (one lane per hit, full any-hit traversals) finishes.
+// The result is exactly that of S independent any-hit searches.
 // --------------------------------------------------------------------------------------------------
 struct SampleRay {
     D3     s, d;        // clipped start (SpatialSubdivision.cs:394) and direction
@@ -274,32 +281,168 @@ __device__ __forceinline__ bool extras_block(const DevScene& sc, D3 rs, D3 rd, C
     return false;
 }
 
-constexpr int kPacketSlots = 2;          // samples per lane: S <= 128
-constexpr int kChunk = 16;               // candidate triangles gathered before the lanes test them
-constexpr int kPacketStack = 96;         // shaft-traversal stack entries per wave (node, t)
+// "does this triangle occlude the sample": the conjunction tri_hit && inside(root) && t + offset <= 1.0 with the
+// cheap rayFrac test moved in front of the barycentric divisions (a conjunction has no evaluation order)
+__device__ __forceinline__ bool tri_blocks(const double* p, const SampleRay& r, const double* lo, const double* hi) {
+    double startDist = r.s.x * p[0] + r.s.y * p[1] + r.s.z * p[2];
+    double dirDist = r.d.x * p[0] + r.d.y * p[1] + r.d.z * p[2];
+    if (dirDist >= 0.0) return false;
+    double rf = p[3] - startDist;
+    if (!(rf <= 0.0)) return false;
+    rf = rf / dirDist;
+    if (!(rf + r.offset <= 1.0)) return false;
+    D3 q = r.s + r.d * rf;
+    if (!inside(lo, hi, q)) return false;
+    D3 w = mk(q.x - p[4], q.y - p[5], q.z - p[6]);
+    double sv = (w.x * p[7] + w.y * p[8] + w.z * p[9]) / p[10];
+    if (sv < 0.0 || sv > 1.0) return false;
+    double tv = (w.x * p[11] + w.y * p[12] + w.z * p[13]) / p[14];
+    return sv >= 0.0 && tv >= 0.0 && sv + tv <= 1.0;
+}
+
+constexpr int kPacketSlots = 2;          // samples per lane in k_shadow_test: S <= 128
+constexpr int kShaftCap = 48;            // triangles per candidate list, round 1 (every hit)
+constexpr int kShaftCap2 = 464;          // round 2 (only hits whose first 48 candidates left samples undecided)
+constexpr int kRecordsPerPass = 16;      // records staged through LDS per pass (2 KB per wave)
+constexpr unsigned kTruncated = 0x80000000u;
+
+// The shaft is parametrised from the surface end: C(u) = E' + u (L - E'), u in [0, 1] (u = 1 - t), so that all fp32
+// quantities are small near the surface point (robust for distant lights); sample rays deviate from C(u) by at most
+// R u.  Can any point of the centre segment, u in [ua, ub], lie within rho of the triangle?  Necessary condition
+// (conservative): the segment meets the slab |n.x - d| <= rho and the three edge half-spaces m_k.x - c_k >= -rho.
+// Each constraint is linear in u, so it clips the interval.
+__device__ __forceinline__ void clip_ge(float f0, float f1, float bound, float& ua, float& ub) {   // f0 + u f1 >= bound
+    if (f1 > 0.0f) ua = fmaxf(ua, (bound - f0) / f1);
+    else if (f1 < 0.0f) ub = fminf(ub, (bound - f0) / f1);
+    else if (!(f0 >= bound)) ub = -1e30f;
+}
+__device__ __forceinline__ bool shaft_touches(const TriSlab s, float ex, float ey, float ez, float dx, float dy, float dz,
+                                              float ua, float ub, float rho) {
+    float f0 = s.n[0] * ex + s.n[1] * ey + s.n[2] * ez - s.d, f1 = s.n[0] * dx + s.n[1] * dy + s.n[2] * dz;
+    clip_ge(f0, f1, -rho, ua, ub);
+    clip_ge(-f0, -f1, -rho, ua, ub);
+    f0 = s.m1[0] * ex + s.m1[1] * ey + s.m1[2] * ez - s.c1; f1 = s.m1[0] * dx + s.m1[1] * dy + s.m1[2] * dz;
+    clip_ge(f0, f1, -rho, ua, ub);
+    f0 = s.m2[0] * ex + s.m2[1] * ey + s.m2[2] * ez - s.c2; f1 = s.m2[0] * dx + s.m2[1] * dy + s.m2[2] * dz;
+    clip_ge(f0, f1, -rho, ua, ub);
+    f0 = s.m3[0] * ex + s.m3[1] * ey + s.m3[2] * ez - s.c3; f1 = s.m3[0] * dx + s.m3[1] * dy + s.m3[2] * dz;
+    clip_ge(f0, f1, -rho, ua, ub);
+    return ua <= ub + 1e-6f;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
+                                               const unsigned int* __restrict__ hit_count, unsigned int count_cap,
+                                               const unsigned int* __restrict__ index_list, int skip, int cap,
+                                               unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
+                                               unsigned long long* stats) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
+    const unsigned int total = min(*hit_count, count_cap);
+    const unsigned int slot_i = blockIdx.x * 256u + (unsigned)tid;       // list slot: the hit itself, or an entry of index_list
+    uint32_t nodes = 0, leaves = 0;
+    if (slot_i < total) {
+        const unsigned int h = index_list ? index_list[slot_i] : slot_i;
+        const HitRec rec = hits[h];
+        const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
+        const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;   // ShadowMethod.cs:151
+        const float R = (float)fc.light_radius * 1.00001f + 1e-30f;
+        float ext = 0.0f;
+        for (int a = 0; a < 3; ++a) ext = fmaxf(ext, (float)(sc.root.max[a] - sc.root.min[a]));
+        const float pad = ext * 3.0517578125e-5f;                          // 2^-15 * extent (boxes carry 2^-16 already)
+        const float pad_tri = ext * 7.62939453125e-6f;                     // 2^-17 * extent: fp32 plane evaluation + fp64 hit-test slack
+        const float ex = (float)(E.x - sc.root.centre[0]), ey = (float)(E.y - sc.root.centre[1]), ez = (float)(E.z - sc.root.centre[2]);
+        const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
+        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
+        int32_t* out = cand + (size_t)slot_i * cap;
+        int count = -skip;             // candidates with ordinal < skip were handled by an earlier round
+        bool truncated = false;
+        int sp = 0;
+        int32_t ni = 0;
+        float nu = 1.0f;               // upper bound of u (distance from the surface end) inside the current subtree
+        for (;;) {
+            const BvhNode n = sc.bnodes[ni];
+            nodes++;
+            const float r = R * fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)) + pad;
+            float elo[3], ehi[3];
+            float a0, b0, a1, b1;      // child u-intervals [a, b]
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { elo[a] = n.lo0[a] - r; ehi[a] = n.hi0[a] + r; }
+            slab(elo, ehi, ex, ey, ez, ix, iy, iz, a0, b0);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { elo[a] = n.lo1[a] - r; ehi[a] = n.hi1[a] + r; }
+            slab(elo, ehi, ex, ey, ez, ix, iy, iz, a1, b1);
+            a0 = fmaxf(a0, umin); a1 = fmaxf(a1, umin);
+            b0 = fminf(b0, nu); b1 = fminf(b1, nu);
+            const bool h0 = n.n0 >= 0 && a0 <= b0, h1 = n.n1 >= 0 && a1 <= b1;
+            // leaves: the one nearest to the surface point first; each triangle is filtered with its fp32 slab record
+            const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
+            if (l0 || l1) {
+                const bool first0 = !l1 || (l0 && a0 <= a1);
+                for (int k = 0; k < 2; ++k) {
+                    const bool use0 = (k == 0) ? first0 : !first0;
+                    if (use0 ? l0 : l1) {
+                        const int first = use0 ? n.c0 : n.c1, cnt = use0 ? n.n0 : n.n1;
+                        const float ua = use0 ? a0 : a1, ub = use0 ? b0 : b1;
+                        const float rho = R * fminf(1.0f, fmaxf(0.0f, ub + 1e-5f)) + pad_tri;
+                        leaves++;
+                        for (int q = 0; q < cnt; ++q) {
+                            if (shaft_touches(sc.bslab[first + q], ex, ey, ez, dx, dy, dz, ua, ub, rho)) {
+                                if (count < cap) { if (count >= 0) out[count] = first + q; count++; }
+                                else truncated = true;
+                            }
+                        }
+                    }
+                }
+                if (truncated) break;
+            }
+            const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
+            if (i0 && i1) {
+                const bool first0 = a0 <= a1;                              // the child nearest to the surface point first
+                st.put(sp++, first0 ? n.c1 : n.c0);
+                st.put(sp++, __float_as_int(first0 ? b1 : b0));
+                ni = first0 ? n.c0 : n.c1; nu = first0 ? b0 : b1;
+            } else if (i0) { ni = n.c0; nu = b0; }
+            else if (i1) { ni = n.c1; nu = b1; }
+            else {
+                if (sp == 0) break;
+                nu = __int_as_float(st.get(--sp));
+                ni = st.get(--sp);
+            }
+        }
+        cand_count[slot_i] = (unsigned)max(count, 0) | (truncated ? kTruncated : 0u);
+    }
+    if (STATS) {
+        uint32_t a = wave_sum(nodes), b = wave_sum(leaves);
+        if (lane == 0) { atomicAdd(&stats[6], (unsigned long long)a); atomicAdd(&stats[7], (unsigned long long)b); }
+    }
+}
+
+// undecided / escaped sample masks of a hit that moves on to the next round
+struct alignas(16) RoundState {
+    unsigned long long alive[kPacketSlots], escaped[kPacketSlots];
+};
 
 template <bool EXTRA, bool STATS>
-__global__ __launch_bounds__(256) void k_shadow_packet(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
-                                                       const HitRec* __restrict__ hits, const unsigned int* __restrict__ hit_count,
-                                                       uint32_t* __restrict__ samples, unsigned long long* stats) {
+__global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
+                                                     const HitRec* __restrict__ hits, const unsigned int* __restrict__ hit_count,
+                                                     unsigned int count_cap, const unsigned int* __restrict__ index_list,
+                                                     const RoundState* __restrict__ state_in, int cap,
+                                                     const unsigned int* __restrict__ cand_count, const int32_t* __restrict__ cand,
+                                                     unsigned int* __restrict__ next_count, unsigned int next_cap,
+                                                     unsigned int* __restrict__ next_list, RoundState* __restrict__ state_out,
+                                                     unsigned int* __restrict__ last_count, unsigned int* __restrict__ last_list,
+                                                     uint32_t* __restrict__ samples, unsigned long long* stats) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // per-wave LDS: candidate chunk + shaft stack
-    int32_t* wl = reinterpret_cast<int32_t*>(lds_pipe) + wave * (kChunk + 8 + 2 * kPacketStack);
-    int32_t* cand = wl;
-    int32_t* stk_n = wl + kChunk + 8;
-    float*   stk_t = reinterpret_cast<float*>(stk_n + kPacketStack);
+    // per-wave LDS: kRecordsPerPass records of 128 B
+    uint4* wrec = reinterpret_cast<uint4*>(lds_pipe) + (size_t)wave * (kRecordsPerPass * 8);
+    const double* wrecd = reinterpret_cast<const double*>(wrec);
 
     const int S = fc.shadow_samples;
-    const unsigned int total = *hit_count;
+    const unsigned int total = min(*hit_count, count_cap);
     const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
-    const float R = (float)fc.light_radius * 1.00001f + 1e-30f;
-    float ext = 0.0f;
-    for (int a = 0; a < 3; ++a) ext = fmaxf(ext, (float)(sc.root.max[a] - sc.root.min[a]));
-    const float pad = ext * 3.0517578125e-5f;                              // 2^-15 * extent (boxes carry 2^-16 already)
-    const float lox = (float)(lpos.x - sc.root.centre[0]), loy = (float)(lpos.y - sc.root.centre[1]), loz = (float)(lpos.z - sc.root.centre[2]);
-
-    // sample offsets of this lane (slot k = sample lane + 64 k)
     D3 off[kPacketSlots];
     bool valid[kPacketSlots];
 #pragma unroll
@@ -309,24 +452,25 @@ __global__ __launch_bounds__(256) void k_shadow_packet(DevScene sc, FrameConst f
         int jj = valid[k] ? j : 0;
         off[k] = mk(offsets[3 * jj], offsets[3 * jj + 1], offsets[3 * jj + 2]);
     }
-
     Ctr sec = {0, 0, 0, 0};
     const unsigned int nwaves = gridDim.x * 4u;
-    for (unsigned int h = blockIdx.x * 4u + (unsigned)wave; h < total; h += nwaves) {
+    for (unsigned int slot_i = blockIdx.x * 4u + (unsigned)wave; slot_i < total; slot_i += nwaves) {
+        const unsigned int h = index_list ? index_list[slot_i] : slot_i;
         const HitRec rec = hits[h];
-        const D3 pos = mk(rec.pos[0], rec.pos[1], rec.pos[2]), nrm = mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]);
-        const D3 E = pos + nrm * 0.001;                                    // shadowRayEnd, ShadowMethod.cs:151
-
+        const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
         SampleRay ray[kPacketSlots];
-        bool alive[kPacketSlots];      // sample still undecided (not blocked yet, may still be hit)
-        bool escaped[kPacketSlots];    // sample that is decided as reaching the surface so far
+        bool alive[kPacketSlots], escaped[kPacketSlots];
 #pragma unroll
         for (int k = 0; k < kPacketSlots; ++k) {
             D3 rs = lpos + off[k];
             D3 rd = E - rs;
             alive[k] = false;
             escaped[k] = valid[k];
-            if (valid[k]) {
+            if (state_in) {                                               // later round: resume from the saved masks
+                const RoundState stt = state_in[slot_i];
+                escaped[k] = ((stt.escaped[k] >> lane) & 1ull) != 0;
+                if (((stt.alive[k] >> lane) & 1ull) != 0) alive[k] = prepare_sample(sc, rs, rd, ray[k]);
+            } else if (valid[k]) {
                 sec.rays++;
                 bool blocked = false;
                 if (EXTRA) blocked = extras_block<EXTRA>(sc, rs, rd, sec);
@@ -334,89 +478,62 @@ __global__ __launch_bounds__(256) void k_shadow_packet(DevScene sc, FrameConst f
                 else alive[k] = prepare_sample(sc, rs, rd, ray[k]);       // outside the root box: nothing can block it
             }
         }
-
-        // ---- shaft walk (wave-uniform) ----
-        const float cdx = (float)(E.x - lpos.x), cdy = (float)(E.y - lpos.y), cdz = (float)(E.z - lpos.z);
-        const float ix = 1.0f / cdx, iy = 1.0f / cdy, iz = 1.0f / cdz;
-        const float tmax = 1.0f + 1e-5f;
-        int sp = 0, ncand = 0;
-        int32_t ni = 0;
-        float nt = 0.0f;               // lower bound of t inside the current subtree
+        const unsigned int cc = cand_count[slot_i];
+        const int ntri = (int)(cc & 0xffffu);
+        const bool truncated = (cc & kTruncated) != 0;
+        const int32_t* list = cand + (size_t)slot_i * cap;
         bool have = __any(alive[0] || alive[1]);
-        while (have) {
-            ni = __builtin_amdgcn_readfirstlane(ni);                       // wave-uniform walk: scalar node fetch
-            nt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nt)));
-            const BvhNode n = sc.bnodes[ni];
-            sec.nodes++;
-            const float r = R * fminf(1.0f, fmaxf(0.0f, 1.0f - nt + 1e-5f)) + pad;
-            float elo[3], ehi[3];
-            float t0, x0, t1, x1;
+        for (int base = 0; base < ntri && have; base += kRecordsPerPass) {
+            const int npass = min(kRecordsPerPass, ntri - base);
+            // ---- stage up to 16 records (2 KB) through LDS: lane -> (record slot, 16-byte piece), coalesced dwordx4 ----
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { elo[a] = n.lo0[a] - r; ehi[a] = n.hi0[a] + r; }
-            slab(elo, ehi, lox, loy, loz, ix, iy, iz, t0, x0);
+            for (int pass = 0; pass < kRecordsPerPass / 8; ++pass) {
+                const int slot = pass * 8 + (lane >> 3);
+                if (slot < npass) wrec[slot * 8 + (lane & 7)] = reinterpret_cast<const uint4*>(&sc.btris[list[base + slot]])[lane & 7];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- every lane tests its undecided samples against the staged records (exact FP64) ----
+            for (int k = 0; k < npass && have; ++k) {
+                const double* p = wrecd + (size_t)k * 16;
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { elo[a] = n.lo1[a] - r; ehi[a] = n.hi1[a] + r; }
-            slab(elo, ehi, lox, loy, loz, ix, iy, iz, t1, x1);
-            t0 = fmaxf(t0, nt); t1 = fmaxf(t1, nt);
-            x0 = fminf(x0, tmax); x1 = fminf(x1, tmax);
-            const bool h0 = n.n0 >= 0 && t0 <= x0, h1 = n.n1 >= 0 && t1 <= x1;
-            if (h0 && n.n0 > 0) { for (int k = 0; k < n.n0; ++k) if (ncand < kChunk + 8) { if (lane == 0) cand[ncand] = n.c0 + k; ncand++; } sec.leaves++; }
-            if (h1 && n.n1 > 0) { for (int k = 0; k < n.n1; ++k) if (ncand < kChunk + 8) { if (lane == 0) cand[ncand] = n.c1 + k; ncand++; } sec.leaves++; }
-            const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
-            bool popped = false;
-            if (i0 && i1) {
-                // visit the child whose interval reaches closest to E' (larger exit t) first
-                const bool first0 = x0 >= x1;
-                if (sp < kPacketStack) { if (lane == 0) { stk_n[sp] = first0 ? n.c1 : n.c0; stk_t[sp] = first0 ? t1 : t0; } sp++; }
-                ni = first0 ? n.c0 : n.c1; nt = first0 ? t0 : t1;
-            } else if (i0) { ni = n.c0; nt = t0; }
-            else if (i1) { ni = n.c1; nt = t1; }
-            else popped = true;
-
-            const bool flush = ncand >= kChunk || (popped && sp == 0);
-            if (flush && ncand > 0) {
-                __builtin_amdgcn_wave_barrier();                           // lane 0's LDS writes are ordered before the reads below
-                // ---- every lane tests its undecided samples against the gathered triangles (exact FP64) ----
-                for (int k = 0; k < ncand; ++k) {
-                    const Rec128* tr = &sc.btris[cand[k]];
-#pragma unroll
-                    for (int q = 0; q < kPacketSlots; ++q) {
-                        if (alive[q]) {
-                            double t; D3 hp;
-                            sec.geom++;
-                            if (tri_hit(tr->p, ray[q].s, ray[q].d, t, hp) && inside(sc.root.lo, sc.root.hi, hp) && (t + ray[q].offset <= 1.0)) {
-                                alive[q] = false;
-                                escaped[q] = false;
-                            }
-                        }
+                for (int q = 0; q < kPacketSlots; ++q) {
+                    if (alive[q]) {
+                        sec.geom++;
+                        if (tri_blocks(p, ray[q], sc.root.lo, sc.root.hi)) { alive[q] = false; escaped[q] = false; }
                     }
                 }
-                ncand = 0;
-                have = __any(alive[0] || alive[1]);
-                if (!have) break;
+                if ((k & 3) == 3) have = __any(alive[0] || alive[1]);
             }
-            if (popped) {
-                if (sp == 0) break;
-                --sp;
-                __builtin_amdgcn_wave_barrier();
-                ni = __builtin_amdgcn_readfirstlane(stk_n[sp]);
-                nt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(stk_t[sp])));
-            }
+            have = __any(alive[0] || alive[1]);
+            __builtin_amdgcn_wave_barrier();
         }
-        const int esc = (int)__popcll(__ballot(escaped[0])) + (int)__popcll(__ballot(escaped[1]));
-        if (lane == 0) {
-            double frac = (double)esc / (double)S;                         // ShadowMethod.IntersectRay :113-119
-            samples[rec.sample] = modulate(samples[rec.sample], to_byte(frac * 255));
+        if (have && truncated) {
+            // the list ran out before the shaft did and some sample is still undecided: next round (longer list),
+            // or -- after the last round / when the next round's buffers are full -- the exact per-lane fallback
+            const unsigned long long a0 = __ballot(alive[0]), a1 = __ballot(alive[1]), e0 = __ballot(escaped[0]), e1 = __ballot(escaped[1]);
+            if (lane == 0) {
+                unsigned int slot = next_count ? atomicAdd(next_count, 1u) : 0xffffffffu;
+                if (slot < next_cap) {
+                    next_list[slot] = h;
+                    RoundState o;
+                    o.alive[0] = a0; o.alive[1] = a1; o.escaped[0] = e0; o.escaped[1] = e1;
+                    state_out[slot] = o;
+                } else {
+                    last_list[atomicAdd(last_count, 1u)] = h;
+                }
+            }
+        } else {
+            const int esc = (int)__popcll(__ballot(escaped[0])) + (int)__popcll(__ballot(escaped[1]));
+            if (lane == 0) {
+                double frac = (double)esc / (double)S;                     // ShadowMethod.IntersectRay :113-119
+                samples[rec.sample] = modulate(samples[rec.sample], to_byte(frac * 255));
+            }
         }
     }
     if (STATS) {
         uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom);
-        if (lane == 0) {
-            atomicAdd(&stats[4], (unsigned long long)a);
-            atomicAdd(&stats[5], (unsigned long long)b);
-            atomicAdd(&stats[6], (unsigned long long)sec.nodes);          // wave-uniform walk: counted once per wave
-            atomicAdd(&stats[7], (unsigned long long)sec.leaves);
-        }
+        if (lane == 0) { atomicAdd(&stats[4], (unsigned long long)a); atomicAdd(&stats[5], (unsigned long long)b); }
     }
 }
 
@@ -458,32 +575,16 @@ static hipError_t launch_primary_t(const PipelineLaunch& L, int row_begin, int r
     size_t lds = (size_t)pipe_stack_levels(L.sc, MODE) * 256 * 4;
     if (L.stats)
         hipLaunchKernelGGL((k_primary<MODE, EXTRA, true>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
-                           samples, (HitRec*)L.hits, L.hit_count, L.stats);
+                           samples, (HitRec*)L.hits, L.counters, L.stats);
     else
         hipLaunchKernelGGL((k_primary<MODE, EXTRA, false>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
-                           samples, (HitRec*)L.hits, L.hit_count, L.stats);
-    return hipGetLastError();
-}
-
-template <bool EXTRA>
-static hipError_t launch_shadow_packet_t(const PipelineLaunch& L, uint32_t* samples, long long max_hits) {
-    size_t lds = 4 * (size_t)(kChunk + 8 + 2 * kPacketStack) * 4;
-    long long want = (max_hits + 3) / 4;
-    unsigned blocks = (unsigned)std::min<long long>(want, (long long)L.persistent_blocks * 2);
-    if (blocks == 0) return hipSuccess;
-    if (L.stats)
-        hipLaunchKernelGGL((k_shadow_packet<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits,
-                           L.hit_count, samples, L.stats);
-    else
-        hipLaunchKernelGGL((k_shadow_packet<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits,
-                           L.hit_count, samples, L.stats);
+                           samples, (HitRec*)L.hits, L.counters, L.stats);
     return hipGetLastError();
 }
 
 template <int MODE, bool EXTRA>
-static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, long long max_hits) {
-    if (MODE == MODE_BVH && (L.fc.flags & 8u) && L.fc.shadow_samples <= 64 * kPacketSlots && L.sc.bdepth + 2 <= kPacketStack && !L.per_lane_shadows)
-        return launch_shadow_packet_t<EXTRA>(L, samples, max_hits);
+static hipError_t launch_shadow_lanes_t(const PipelineLaunch& L, uint32_t* samples, long long max_hits, const unsigned int* count,
+                                        unsigned int* head, const unsigned int* index_list) {
     int levels = pipe_stack_levels(L.sc, MODE);
     size_t lds = (((size_t)levels * 256 * 4 + 15) & ~(size_t)15) + (size_t)L.fc.shadow_samples * 3 * sizeof(double);
     long long want = (max_hits + 255) / 256;
@@ -491,11 +592,77 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
     if (blocks == 0) return hipSuccess;
     if (L.stats)
         hipLaunchKernelGGL((k_shadow<MODE, EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits,
-                           L.hit_count, L.work_head, samples, levels, L.stats);
+                           count, head, index_list, samples, levels, L.stats);
     else
         hipLaunchKernelGGL((k_shadow<MODE, EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits,
-                           L.hit_count, L.work_head, samples, levels, L.stats);
+                           count, head, index_list, samples, levels, L.stats);
     return hipGetLastError();
+}
+
+static void pipe_events(const PipelineLaunch& L, int kid, hipEvent_t& e0, hipEvent_t& e1) {
+    e0 = e1 = nullptr;
+    if (L.get_events) L.get_events(L.user, kid, &e0, &e1);
+}
+
+// counters: [0] hit_count  [1] k_shadow work head  [2] fallback_count  [3] fallback work head
+template <int MODE, bool EXTRA>
+static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, long long max_hits) {
+    hipError_t e;
+    hipEvent_t e0, e1;
+    const bool shaft = MODE == MODE_BVH && (L.fc.flags & 8u) && L.fc.shadow_samples <= 64 * kPacketSlots && !L.per_lane_shadows && L.cand;
+    if (!shaft) {
+        pipe_events(L, K_SHADOW, e0, e1);
+        if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
+        e = launch_shadow_lanes_t<MODE, EXTRA>(L, samples, max_hits, L.counters, L.counters + 1, nullptr);
+        if (e != hipSuccess) return e;
+        if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
+        return hipSuccess;
+    }
+    // counters: [0] hits  [1] k_shadow head  [2] round-2 count  [3] fallback count  [4] fallback head
+    const unsigned r2cap = L.round2_cap;
+    for (int round = 1; round <= 2; ++round) {
+        const bool r1 = round == 1;
+        const unsigned int* count_ptr = r1 ? L.counters : L.counters + 2;
+        const unsigned count_cap = r1 ? 0xffffffffu : r2cap;
+        const unsigned int* ilist = r1 ? nullptr : L.round2_list;
+        const long long max_items = r1 ? max_hits : (long long)std::min<long long>(max_hits, r2cap);
+        if (max_items <= 0) break;
+        const int skip = r1 ? 0 : kShaftCap, cap = r1 ? kShaftCap : kShaftCap2;
+        unsigned int* ccount = r1 ? L.cand_count : L.cand_count2;
+        int32_t* clist = r1 ? L.cand : L.cand2;
+        // ---- k_shaft ----
+        pipe_events(L, K_SHAFT, e0, e1);
+        if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
+        {
+            size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
+            unsigned blocks = (unsigned)((max_items + 255) / 256);
+            if (L.stats) hipLaunchKernelGGL((k_shaft<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, ccount, clist, L.stats);
+            else hipLaunchKernelGGL((k_shaft<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, ccount, clist, L.stats);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
+        // ---- k_shadow_test ----
+        pipe_events(L, K_SHADOW, e0, e1);
+        if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
+        {
+            size_t lds = 4 * (size_t)kRecordsPerPass * 128;
+            long long want = (max_items + 3) / 4;
+            unsigned blocks = (unsigned)std::min<long long>(want, (long long)L.persistent_blocks * 2);
+            const RoundState* st_in = r1 ? nullptr : (const RoundState*)L.round2_state;
+            unsigned int* next_count = r1 ? L.counters + 2 : nullptr;
+            if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, count_ptr, count_cap, ilist, st_in, cap, ccount, clist, next_count, r2cap, L.round2_list, (RoundState*)L.round2_state, L.counters + 3, L.fallback, samples, L.stats);
+            else hipLaunchKernelGGL((k_shadow_test<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, count_ptr, count_cap, ilist, st_in, cap, ccount, clist, next_count, r2cap, L.round2_list, (RoundState*)L.round2_state, L.counters + 3, L.fallback, samples, L.stats);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
+    }
+    // ---- fallback: hits that are still undecided after the longest list ----
+    pipe_events(L, K_FALLBACK, e0, e1);
+    if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
+    e = launch_shadow_lanes_t<MODE, EXTRA>(L, samples, max_hits, L.counters + 3, L.counters + 4, L.fallback);
+    if (e != hipSuccess) return e;
+    if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
+    return hipSuccess;
 }
 
 template <int MODE, bool EXTRA>
@@ -508,7 +675,7 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
         uint32_t* samples = (n2 == 1) ? L.pixels : L.samples;
         hipError_t e;
         if (shadows) {
-            e = hipMemsetAsync(L.hit_count, 0, 2 * sizeof(unsigned int), L.stream);     // hit_count, work_head (adjacent)
+            e = hipMemsetAsync(L.counters, 0, 8 * sizeof(unsigned int), L.stream);
             if (e != hipSuccess) return e;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -518,12 +685,8 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
         if (e != hipSuccess) return e;
         if (e1) { e = hipEventRecord(e1, L.stream); if (e != hipSuccess) return e; }
         if (shadows) {
-            e0 = e1 = nullptr;
-            if (L.get_events) L.get_events(L.user, K_SHADOW, &e0, &e1);
-            if (e0) { e = hipEventRecord(e0, L.stream); if (e != hipSuccess) return e; }
             e = launch_shadow_t<MODE, EXTRA>(L, samples, (long long)row_count * L.fc.width * n2);
             if (e != hipSuccess) return e;
-            if (e1) { e = hipEventRecord(e1, L.stream); if (e != hipSuccess) return e; }
         }
         if (n2 > 1) {
             e0 = e1 = nullptr;
@@ -551,5 +714,9 @@ hipError_t launch_pipeline(const PipelineLaunch& L) {
 }
 
 size_t pipeline_hit_record_bytes() { return sizeof(HitRec); }
+size_t pipeline_shaft_bytes_per_hit() { return (size_t)kShaftCap * 4 + 8; }
+int pipeline_shaft_cap() { return kShaftCap; }
+int pipeline_shaft_cap2() { return kShaftCap2; }
+size_t pipeline_round_state_bytes() { return sizeof(RoundState); }
 
 }  // namespace sr

@@ -53,6 +53,19 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
+// fp32 conservative description of one triangle for the shadow-shaft walk (64 B = one line), in coordinates
+// relative to the root-box centre: the plane (unit normal n, offset d) and the three edge planes (unit in-plane
+// normals m_k pointing inward, offsets c_k).  A point within distance rho of the triangle satisfies
+// |n.x - d| <= rho and m_k.x - c_k >= -rho for k = 1..3 (the mitred offset polygon contains the rounded one).
+// Degenerate triangles store all zeros: every test passes.
+struct alignas(16) TriSlab {
+    float n[3], d;
+    float m1[3], c1;
+    float m2[3], c2;
+    float m3[3], c3;
+};
+static_assert(sizeof(TriSlab) == 64, "TriSlab must be 64 bytes");
+
 // Root box as the clip needs it (AxisAlignedBox.cs:16-28,143-149)
 struct RootBox {
     double min[3], max[3];       // model.Min / model.Max
@@ -80,6 +93,7 @@ struct FrameConst {
     double   light_dir_model[3], light_pos_model[3];
     double   start_world[3];     // R^-1 * (0,0,-Position.z), Renderer.cs:1717
     double   aspect;             // (double)height / (double)width, Renderer.cs:621
+    int32_t  debug, debug_pad;   // SR_DEBUG experiment switch (0 in production)
     double   light_radius;       // max |area-light offset| (0.2 for the reference table): bounds the shadow shaft
 };
 

@@ -100,6 +100,11 @@ class GpuScene:
         _check(_lib.lib().sr_last_ray_stats(self._h, _p(out)))
         return out
 
+    def debug_counters(self):
+        out = np.zeros(8, dtype=np.uint32)
+        _check(_lib.lib().sr_debug_counters(self._h, _p(out)))
+        return [int(x) for x in out]
+
     def reset_kernel_times(self):
         _lib.lib().sr_reset_kernel_times(self._h)
 
