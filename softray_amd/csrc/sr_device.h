@@ -26,7 +26,7 @@ struct DevScene {
     RootBox        root;
 };
 
-enum KernelId { K_RENDER = 0, K_TRACE = 1, K_PRIMARY = 2, K_SHADOW = 3, K_RESOLVE = 4, K_SHAFT = 5, K_FALLBACK = 6, K_COUNT = 7 };
+enum KernelId { K_RENDER = 0, K_TRACE = 1, K_PRIMARY = 2, K_SHADOW = 3, K_RESOLVE = 4, K_SHAFT = 5, K_FALLBACK = 6, K_SHAFT2 = 7, K_SHADOW2 = 8, K_COUNT = 9 };
 const char* kernel_name(int id);
 
 struct RenderLaunch {

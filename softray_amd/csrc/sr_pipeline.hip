@@ -311,23 +311,45 @@ constexpr unsigned kTruncated = 0x80000000u;
 // R u.  Can any point of the centre segment, u in [ua, ub], lie within rho of the triangle?  Necessary condition
 // (conservative): the segment meets the slab |n.x - d| <= rho and the three edge half-spaces m_k.x - c_k >= -rho.
 // Each constraint is linear in u, so it clips the interval.
-__device__ __forceinline__ void clip_ge(float f0, float f1, float bound, float& ua, float& ub) {   // f0 + u f1 >= bound
-    if (f1 > 0.0f) ua = fmaxf(ua, (bound - f0) / f1);
-    else if (f1 < 0.0f) ub = fminf(ub, (bound - f0) / f1);
-    else if (!(f0 >= bound)) ub = -1e30f;
+// one linear constraint f0 + u f1 >= bound, with the reciprocal of f1 precomputed (v_rcp_f32: 1 ulp, far inside the
+// 1e-6 slack of the final comparison)
+struct Lin {
+    float f0, inv;      // inv = 1/f1, or 0 when f1 == 0
+    int   sgn;          // sign of f1: +1, -1, 0
+};
+__device__ __forceinline__ Lin make_lin(float f0, float f1) {
+    Lin l;
+    l.f0 = f0;
+    l.sgn = (f1 > 0.0f) ? 1 : ((f1 < 0.0f) ? -1 : 0);
+    l.inv = l.sgn ? __builtin_amdgcn_rcpf(f1) : 0.0f;
+    return l;
+}
+__device__ __forceinline__ void clip_ge(const Lin& l, float bound, float& ua, float& ub) {
+    const float v = (bound - l.f0) * l.inv;
+    if (l.sgn > 0) ua = fmaxf(ua, v);
+    else if (l.sgn < 0) ub = fminf(ub, v);
+    else if (!(l.f0 >= bound)) ub = -1e30f;
 }
 __device__ __forceinline__ bool shaft_touches(const TriSlab s, float ex, float ey, float ez, float dx, float dy, float dz,
-                                              float ua, float ub, float rho) {
-    float f0 = s.n[0] * ex + s.n[1] * ey + s.n[2] * ez - s.d, f1 = s.n[0] * dx + s.n[1] * dy + s.n[2] * dz;
-    clip_ge(f0, f1, -rho, ua, ub);
-    clip_ge(-f0, -f1, -rho, ua, ub);
-    f0 = s.m1[0] * ex + s.m1[1] * ey + s.m1[2] * ez - s.c1; f1 = s.m1[0] * dx + s.m1[1] * dy + s.m1[2] * dz;
-    clip_ge(f0, f1, -rho, ua, ub);
-    f0 = s.m2[0] * ex + s.m2[1] * ey + s.m2[2] * ez - s.c2; f1 = s.m2[0] * dx + s.m2[1] * dy + s.m2[2] * dz;
-    clip_ge(f0, f1, -rho, ua, ub);
-    f0 = s.m3[0] * ex + s.m3[1] * ey + s.m3[2] * ez - s.c3; f1 = s.m3[0] * dx + s.m3[1] * dy + s.m3[2] * dz;
-    clip_ge(f0, f1, -rho, ua, ub);
-    return ua <= ub + 1e-6f;
+                                              float ua, float ub, float R, float pad) {
+    const float n0 = s.n[0] * ex + s.n[1] * ey + s.n[2] * ez - s.d, n1 = s.n[0] * dx + s.n[1] * dy + s.n[2] * dz;
+    const Lin ln = make_lin(n0, n1), lm = make_lin(-n0, -n1);
+    const Lin l1 = make_lin(s.m1[0] * ex + s.m1[1] * ey + s.m1[2] * ez - s.c1, s.m1[0] * dx + s.m1[1] * dy + s.m1[2] * dz);
+    const Lin l2 = make_lin(s.m2[0] * ex + s.m2[1] * ey + s.m2[2] * ez - s.c2, s.m2[0] * dx + s.m2[1] * dy + s.m2[2] * dz);
+    const Lin l3 = make_lin(s.m3[0] * ex + s.m3[1] * ey + s.m3[2] * ez - s.c3, s.m3[0] * dx + s.m3[1] * dy + s.m3[2] * dz);
+    // the shaft radius at the far end of the current interval bounds the deviation; clipping shrinks the interval,
+    // which shrinks the radius: one refinement
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const float rho = R * fminf(1.0f, fmaxf(0.0f, ub + 1e-5f)) + pad;
+        clip_ge(ln, -rho, ua, ub);
+        clip_ge(lm, -rho, ua, ub);
+        clip_ge(l1, -rho, ua, ub);
+        clip_ge(l2, -rho, ua, ub);
+        clip_ge(l3, -rho, ua, ub);
+        if (!(ua <= ub + 1e-6f)) return false;
+    }
+    return true;
 }
 
 template <bool STATS>
@@ -385,10 +407,9 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                     if (use0 ? l0 : l1) {
                         const int first = use0 ? n.c0 : n.c1, cnt = use0 ? n.n0 : n.n1;
                         const float ua = use0 ? a0 : a1, ub = use0 ? b0 : b1;
-                        const float rho = R * fminf(1.0f, fmaxf(0.0f, ub + 1e-5f)) + pad_tri;
                         leaves++;
                         for (int q = 0; q < cnt; ++q) {
-                            if (shaft_touches(sc.bslab[first + q], ex, ey, ez, dx, dy, dz, ua, ub, rho)) {
+                            if (shaft_touches(sc.bslab[first + q], ex, ey, ez, dx, dy, dz, ua, ub, R, pad_tri)) {
                                 if (count < cap) { if (count >= 0) out[count] = first + q; count++; }
                                 else truncated = true;
                             }
@@ -631,7 +652,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         unsigned int* ccount = r1 ? L.cand_count : L.cand_count2;
         int32_t* clist = r1 ? L.cand : L.cand2;
         // ---- k_shaft ----
-        pipe_events(L, K_SHAFT, e0, e1);
+        pipe_events(L, r1 ? K_SHAFT : K_SHAFT2, e0, e1);
         if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
         {
             size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
@@ -642,7 +663,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         }
         if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
         // ---- k_shadow_test ----
-        pipe_events(L, K_SHADOW, e0, e1);
+        pipe_events(L, r1 ? K_SHADOW : K_SHADOW2, e0, e1);
         if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
         {
             size_t lds = 4 * (size_t)kRecordsPerPass * 128;

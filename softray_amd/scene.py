@@ -110,8 +110,8 @@ class GpuScene:
 
     def kernel_times(self):
         """{kernel: (total ms, launches)} since reset_kernel_times() -- HIP events on the launch stream."""
-        arr = (KernelTime * 8)()
-        n = _lib.lib().sr_kernel_times(self._h, arr, 8)
+        arr = (KernelTime * 16)()
+        n = _lib.lib().sr_kernel_times(self._h, arr, 16)
         return {arr[i].name.decode(): (float(arr[i].ms), int(arr[i].launches)) for i in range(n)}
 
     # ---- IRayIntersectable.IntersectRay, batched ----
