@@ -71,7 +71,7 @@ struct sr_scene {
     sr::Bvh     bvh;
     // device state
     DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab;
-    DBuf d_offsets, d_rowmap, d_pixels, d_stats, d_io[9], d_hits, d_samples, d_counters, d_cand_count, d_cand, d_fallback, d_r2list, d_r2state, d_cand_count2, d_cand2;
+    DBuf d_offsets, d_rowmap, d_pixels, d_stats, d_io[9], d_hits, d_samples, d_counters, d_fallback, d_rlist[sr::kShaftRounds], d_rstate[sr::kShaftRounds], d_rcount[sr::kShaftRounds], d_rcand[sr::kShaftRounds];
     int num_cus = 0;
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
     std::vector<double>  offsets_host;
@@ -261,17 +261,20 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     long long band_rows = std::max<long long>(16, (kMaxBandSamples / ((long long)fc.width * n2)) / 16 * 16);
     band_rows = std::min<long long>(band_rows, ((long long)fc.num_rows + 15) / 16 * 16);
     const long long band_samples = band_rows * fc.width * n2;
-    unsigned round2_cap = 0;
     if (shadows) SR_HIP(s->d_hits.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
+    unsigned round_items[sr::kShaftRounds] = {};
     if (shaft) {
-        SR_HIP(s->d_cand_count.reserve((size_t)band_samples * 4));
-        SR_HIP(s->d_cand.reserve((size_t)band_samples * sr::pipeline_shaft_cap() * 4));
         SR_HIP(s->d_fallback.reserve((size_t)band_samples * 4));
-        round2_cap = (unsigned)std::max<long long>(1024, band_samples / 8);
-        SR_HIP(s->d_r2list.reserve((size_t)round2_cap * 4));
-        SR_HIP(s->d_r2state.reserve((size_t)round2_cap * sr::pipeline_round_state_bytes()));
-        SR_HIP(s->d_cand_count2.reserve((size_t)round2_cap * 4));
-        SR_HIP(s->d_cand2.reserve((size_t)round2_cap * sr::pipeline_shaft_cap2() * 4));
+        for (int r = 0; r < sr::kShaftRounds; ++r) {
+            // round 0 sees every hit; each later round is provisioned for 1/8 of the previous one
+            round_items[r] = r == 0 ? (unsigned)band_samples : (unsigned)std::max<long long>(1024, (long long)round_items[r - 1] / (r == 1 ? 8 : 4));
+            SR_HIP(s->d_rcount[r].reserve((size_t)round_items[r] * 4));
+            SR_HIP(s->d_rcand[r].reserve((size_t)round_items[r] * sr::pipeline_round_cap(r) * 4));
+            if (r > 0) {
+                SR_HIP(s->d_rlist[r].reserve((size_t)round_items[r] * 4));
+                SR_HIP(s->d_rstate[r].reserve((size_t)round_items[r] * sr::pipeline_round_state_bytes()));
+            }
+        }
     }
     if (n2 > 1) SR_HIP(s->d_samples.reserve((size_t)band_samples * 4));
     SR_HIP(s->d_counters.reserve(64));
@@ -290,14 +293,14 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     P.samples = (uint32_t*)s->d_samples.p;
     P.hits = s->d_hits.p;
     P.counters = (unsigned int*)s->d_counters.p;
-    P.cand_count = shaft ? (unsigned int*)s->d_cand_count.p : nullptr;
-    P.cand = shaft ? (int32_t*)s->d_cand.p : nullptr;
     P.fallback = shaft ? (unsigned int*)s->d_fallback.p : nullptr;
-    P.round2_cap = round2_cap;
-    P.round2_list = (unsigned int*)s->d_r2list.p;
-    P.round2_state = s->d_r2state.p;
-    P.cand_count2 = (unsigned int*)s->d_cand_count2.p;
-    P.cand2 = (int32_t*)s->d_cand2.p;
+    for (int r = 0; r < sr::kShaftRounds; ++r) {
+        P.round_items[r] = round_items[r];
+        P.round_list[r] = (shaft && r > 0) ? (unsigned int*)s->d_rlist[r].p : nullptr;
+        P.round_state[r] = (shaft && r > 0) ? s->d_rstate[r].p : nullptr;
+        P.round_cand_count[r] = shaft ? (unsigned int*)s->d_rcount[r].p : nullptr;
+        P.round_cand[r] = shaft ? (int32_t*)s->d_rcand[r].p : nullptr;
+    }
     P.band_rows = (int32_t)band_rows;
     P.persistent_blocks = s->num_cus * 8;
     P.per_lane_shadows = (f->flags & SR_F_PER_LANE_SHADOWS) != 0;
@@ -342,8 +345,9 @@ void sr_destroy(sr_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
-                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_cand_count, &s->d_cand, &s->d_fallback, &s->d_r2list, &s->d_r2state, &s->d_cand_count2, &s->d_cand2};
+                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_fallback};
         for (DBuf* b : bufs) b->release();
+        for (int r = 0; r < sr::kShaftRounds; ++r) { s->d_rlist[r].release(); s->d_rstate[r].release(); s->d_rcount[r].release(); s->d_rcand[r].release(); }
         for (DBuf& b : s->d_io) b.release();
         for (int k = 0; k < sr::K_COUNT; ++k)
             for (hipEvent_t e : s->ev[k]) (void)hipEventDestroy(e);

@@ -26,6 +26,7 @@ struct DevScene {
     RootBox        root;
 };
 
+constexpr int kShaftRounds = 2;
 enum KernelId { K_RENDER = 0, K_TRACE = 1, K_PRIMARY = 2, K_SHADOW = 3, K_RESOLVE = 4, K_SHAFT = 5, K_FALLBACK = 6, K_SHAFT2 = 7, K_SHADOW2 = 8, K_COUNT = 9 };
 const char* kernel_name(int id);
 
@@ -53,15 +54,14 @@ struct PipelineLaunch {
     uint32_t*   pixels;         // device output frame (full surface or compact strips)
     uint32_t*   samples;        // device [band_rows * width * n^2] sample colours (sub_pixel_res > 1 only)
     void*       hits;           // device hit queue, band_rows * width * n^2 records of pipeline_hit_record_bytes()
-    unsigned int* counters;     // device uint[8]: hits, k_shadow head, round-2 count, fallback count, fallback head
-    unsigned int* cand_count;   // device [band samples]: shaft candidate-list length | truncated flag (nullptr: no shaft path)
-    int32_t*    cand;           // device [band samples][pipeline_shaft_cap()]
+    unsigned int* counters;     // device uint[8]: hits, k_shadow head, items entering round 1.., fallback count, fallback head
+    // shaft path (own BVH + point light), kShaftRounds rounds of (k_shaft, k_shadow_test); round 0 covers every hit
+    unsigned int  round_items[kShaftRounds];      // capacity (hits) of the round's buffers (round 0: band samples)
+    unsigned int* round_list[kShaftRounds];       // device hit indices entering the round (round 0: nullptr = identity)
+    void*         round_state[kShaftRounds];      // device RoundState per item (round 0: nullptr)
+    unsigned int* round_cand_count[kShaftRounds]; // device per-item candidate count | truncated flag
+    int32_t*      round_cand[kShaftRounds];       // device [items][pipeline_round_cap(round)] (round_cand[0] == nullptr: no shaft path)
     unsigned int* fallback;     // device [band samples]: hits that need the exact per-lane fallback
-    unsigned int  round2_cap;   // capacity (hits) of the round-2 buffers below
-    unsigned int* round2_list;  // device [round2_cap] hit indices
-    void*         round2_state; // device [round2_cap] RoundState
-    unsigned int* cand_count2;  // device [round2_cap]
-    int32_t*      cand2;        // device [round2_cap][pipeline_shaft_cap2()]
     int32_t     band_rows;      // rows per band (multiple of 16)
     int32_t     persistent_blocks;
     bool        per_lane_shadows; // force k_shadow (one lane per hit) instead of k_shadow_packet (cross-check)
@@ -72,9 +72,7 @@ struct PipelineLaunch {
 };
 hipError_t launch_pipeline(const PipelineLaunch& L);
 size_t pipeline_hit_record_bytes();
-size_t pipeline_shaft_bytes_per_hit();
-int pipeline_shaft_cap();
-int pipeline_shaft_cap2();
+int pipeline_round_cap(int round);
 size_t pipeline_round_state_bytes();
 
 struct TraceLaunch {

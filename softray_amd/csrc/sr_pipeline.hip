@@ -301,8 +301,9 @@ __device__ __forceinline__ bool tri_blocks(const double* p, const SampleRay& r, 
 }
 
 constexpr int kPacketSlots = 2;          // samples per lane in k_shadow_test: S <= 128
-constexpr int kShaftCap = 48;            // triangles per candidate list, round 1 (every hit)
-constexpr int kShaftCap2 = 464;          // round 2 (only hits whose first 48 candidates left samples undecided)
+constexpr int kShaftCap = 48;            // triangles per candidate list in the first round (every hit)
+// later rounds only see the hits whose earlier candidates left samples undecided: longer lists, fewer hits
+constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 160};
 constexpr int kRecordsPerPass = 16;      // records staged through LDS per pass (2 KB per wave)
 constexpr unsigned kTruncated = 0x80000000u;
 
@@ -479,6 +480,11 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
         const unsigned int h = index_list ? index_list[slot_i] : slot_i;
         const HitRec rec = hits[h];
         const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
+        const unsigned int cc = cand_count[slot_i];
+        const int ntri = (int)(cc & 0xffffu);
+        const bool truncated = (cc & kTruncated) != 0;
+        const int32_t* list = cand + (size_t)slot_i * cap;
+        const bool work = ntri > 0 || truncated;      // an empty, complete list: every sample escapes, no clipping needed
         SampleRay ray[kPacketSlots];
         bool alive[kPacketSlots], escaped[kPacketSlots];
 #pragma unroll
@@ -490,19 +496,15 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
             if (state_in) {                                               // later round: resume from the saved masks
                 const RoundState stt = state_in[slot_i];
                 escaped[k] = ((stt.escaped[k] >> lane) & 1ull) != 0;
-                if (((stt.alive[k] >> lane) & 1ull) != 0) alive[k] = prepare_sample(sc, rs, rd, ray[k]);
+                if (work && ((stt.alive[k] >> lane) & 1ull) != 0) alive[k] = prepare_sample(sc, rs, rd, ray[k]);
             } else if (valid[k]) {
                 sec.rays++;
                 bool blocked = false;
                 if (EXTRA) blocked = extras_block<EXTRA>(sc, rs, rd, sec);
                 if (blocked) escaped[k] = false;
-                else alive[k] = prepare_sample(sc, rs, rd, ray[k]);       // outside the root box: nothing can block it
+                else if (work) alive[k] = prepare_sample(sc, rs, rd, ray[k]);   // outside the root box: nothing can block it
             }
         }
-        const unsigned int cc = cand_count[slot_i];
-        const int ntri = (int)(cc & 0xffffu);
-        const bool truncated = (cc & kTruncated) != 0;
-        const int32_t* list = cand + (size_t)slot_i * cap;
         bool have = __any(alive[0] || alive[1]);
         for (int base = 0; base < ntri && have; base += kRecordsPerPass) {
             const int npass = min(kRecordsPerPass, ntri - base);
@@ -555,6 +557,51 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
     if (STATS) {
         uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom);
         if (lane == 0) { atomicAdd(&stats[4], (unsigned long long)a); atomicAdd(&stats[5], (unsigned long long)b); }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_shadow_wave: exact fallback of the shaft path.  wave = hit point, lanes = area-light samples, every lane runs
+// full any-hit BVH traversals for its 1-2 samples (the lanes' rays converge on one point, so the walks are coherent).
+// Only the few hit points whose candidate lists overflowed in every round get here.
+// --------------------------------------------------------------------------------------------------
+template <bool EXTRA, bool STATS>
+__global__ __launch_bounds__(256) void k_shadow_wave(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
+                                                     const HitRec* __restrict__ hits, const unsigned int* __restrict__ count,
+                                                     const unsigned int* __restrict__ index_list, uint32_t* __restrict__ samples,
+                                                     unsigned long long* stats) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
+    const int S = fc.shadow_samples;
+    const unsigned int total = *count;
+    const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
+    Ctr sec = {0, 0, 0, 0};
+    const unsigned int nwaves = gridDim.x * 4u;
+    for (unsigned int i = blockIdx.x * 4u + (unsigned)wave; i < total; i += nwaves) {
+        const HitRec rec = hits[index_list[i]];
+        const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
+        int esc = 0;
+        for (int j = lane; j < S; j += 64) {
+            D3 rs = lpos + mk(offsets[3 * j], offsets[3 * j + 1], offsets[3 * j + 2]);
+            D3 rd = E - rs;
+            Hit h;
+            sec.rays++;
+            bool blocked = root_intersect<MODE_BVH, true, EXTRA>(sc, sc.tris, sc.extra, st, rs, rd, h, sec) && !(h.t > 1.0);
+            if (!blocked) esc++;
+        }
+        esc = (int)wave_sum((uint32_t)esc);
+        if (lane == 0) {
+            double frac = (double)esc / (double)S;
+            samples[rec.sample] = modulate(samples[rec.sample], to_byte(frac * 255));
+        }
+    }
+    if (STATS) {
+        uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom), c2 = wave_sum(sec.nodes), d2 = wave_sum(sec.leaves);
+        if (lane == 0) {
+            atomicAdd(&stats[4], (unsigned long long)a); atomicAdd(&stats[5], (unsigned long long)b);
+            atomicAdd(&stats[6], (unsigned long long)c2); atomicAdd(&stats[7], (unsigned long long)d2);
+        }
     }
 }
 
@@ -630,7 +677,7 @@ template <int MODE, bool EXTRA>
 static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, long long max_hits) {
     hipError_t e;
     hipEvent_t e0, e1;
-    const bool shaft = MODE == MODE_BVH && (L.fc.flags & 8u) && L.fc.shadow_samples <= 64 * kPacketSlots && !L.per_lane_shadows && L.cand;
+    const bool shaft = MODE == MODE_BVH && (L.fc.flags & 8u) && L.fc.shadow_samples <= 64 * kPacketSlots && !L.per_lane_shadows && L.round_cand[0];
     if (!shaft) {
         pipe_events(L, K_SHADOW, e0, e1);
         if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
@@ -639,49 +686,57 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
         return hipSuccess;
     }
-    // counters: [0] hits  [1] k_shadow head  [2] round-2 count  [3] fallback count  [4] fallback head
-    const unsigned r2cap = L.round2_cap;
-    for (int round = 1; round <= 2; ++round) {
-        const bool r1 = round == 1;
-        const unsigned int* count_ptr = r1 ? L.counters : L.counters + 2;
-        const unsigned count_cap = r1 ? 0xffffffffu : r2cap;
-        const unsigned int* ilist = r1 ? nullptr : L.round2_list;
-        const long long max_items = r1 ? max_hits : (long long)std::min<long long>(max_hits, r2cap);
+    // counters: [0] hits  [1] k_shadow head  [2..] items entering round 1, 2, ..  [2+R-1] fallback count  [2+R] fallback head
+    unsigned int* fb_count = L.counters + 2 + (kShaftRounds - 1);
+    int skip = 0;
+    for (int round = 0; round < kShaftRounds; ++round) {
+        const bool first = round == 0, last = round == kShaftRounds - 1;
+        const unsigned int* count_ptr = first ? L.counters : L.counters + 1 + round;
+        const unsigned count_cap = first ? 0xffffffffu : L.round_items[round];
+        const unsigned int* ilist = first ? nullptr : L.round_list[round];
+        const long long max_items = first ? max_hits : (long long)std::min<long long>(max_hits, count_cap);
         if (max_items <= 0) break;
-        const int skip = r1 ? 0 : kShaftCap, cap = r1 ? kShaftCap : kShaftCap2;
-        unsigned int* ccount = r1 ? L.cand_count : L.cand_count2;
-        int32_t* clist = r1 ? L.cand : L.cand2;
+        const int cap = kRoundCap[round];
         // ---- k_shaft ----
-        pipe_events(L, r1 ? K_SHAFT : K_SHAFT2, e0, e1);
+        pipe_events(L, first ? K_SHAFT : K_SHAFT2, e0, e1);
         if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
         {
             size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
             unsigned blocks = (unsigned)((max_items + 255) / 256);
-            if (L.stats) hipLaunchKernelGGL((k_shaft<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, ccount, clist, L.stats);
-            else hipLaunchKernelGGL((k_shaft<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, ccount, clist, L.stats);
+            if (L.stats) hipLaunchKernelGGL((k_shaft<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, L.round_cand_count[round], L.round_cand[round], L.stats);
+            else hipLaunchKernelGGL((k_shaft<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, L.round_cand_count[round], L.round_cand[round], L.stats);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
         // ---- k_shadow_test ----
-        pipe_events(L, r1 ? K_SHADOW : K_SHADOW2, e0, e1);
+        pipe_events(L, first ? K_SHADOW : K_SHADOW2, e0, e1);
         if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
         {
             size_t lds = 4 * (size_t)kRecordsPerPass * 128;
             long long want = (max_items + 3) / 4;
             unsigned blocks = (unsigned)std::min<long long>(want, (long long)L.persistent_blocks * 2);
-            const RoundState* st_in = r1 ? nullptr : (const RoundState*)L.round2_state;
-            unsigned int* next_count = r1 ? L.counters + 2 : nullptr;
-            if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, count_ptr, count_cap, ilist, st_in, cap, ccount, clist, next_count, r2cap, L.round2_list, (RoundState*)L.round2_state, L.counters + 3, L.fallback, samples, L.stats);
-            else hipLaunchKernelGGL((k_shadow_test<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, count_ptr, count_cap, ilist, st_in, cap, ccount, clist, next_count, r2cap, L.round2_list, (RoundState*)L.round2_state, L.counters + 3, L.fallback, samples, L.stats);
+            const RoundState* st_in = first ? nullptr : (const RoundState*)L.round_state[round];
+            unsigned int* next_count = last ? nullptr : L.counters + 2 + round;
+            const unsigned next_cap = last ? 0u : L.round_items[round + 1];
+            unsigned int* next_list = last ? nullptr : L.round_list[round + 1];
+            RoundState* st_out = last ? nullptr : (RoundState*)L.round_state[round + 1];
+            if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, count_ptr, count_cap, ilist, st_in, cap, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, samples, L.stats);
+            else hipLaunchKernelGGL((k_shadow_test<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, count_ptr, count_cap, ilist, st_in, cap, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, samples, L.stats);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
+        skip += cap;
     }
     // ---- fallback: hits that are still undecided after the longest list ----
     pipe_events(L, K_FALLBACK, e0, e1);
     if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
-    e = launch_shadow_lanes_t<MODE, EXTRA>(L, samples, max_hits, L.counters + 3, L.counters + 4, L.fallback);
-    if (e != hipSuccess) return e;
+    {
+        size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
+        unsigned blocks = (unsigned)std::min<long long>((max_hits + 3) / 4, (long long)L.persistent_blocks * 2);
+        if (L.stats) hipLaunchKernelGGL((k_shadow_wave<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, fb_count, L.fallback, samples, L.stats);
+        else hipLaunchKernelGGL((k_shadow_wave<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, fb_count, L.fallback, samples, L.stats);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
     return hipSuccess;
 }
@@ -735,9 +790,7 @@ hipError_t launch_pipeline(const PipelineLaunch& L) {
 }
 
 size_t pipeline_hit_record_bytes() { return sizeof(HitRec); }
-size_t pipeline_shaft_bytes_per_hit() { return (size_t)kShaftCap * 4 + 8; }
-int pipeline_shaft_cap() { return kShaftCap; }
-int pipeline_shaft_cap2() { return kShaftCap2; }
+int pipeline_round_cap(int round) { return kRoundCap[round]; }
 size_t pipeline_round_state_bytes() { return sizeof(RoundState); }
 
 }  // namespace sr
