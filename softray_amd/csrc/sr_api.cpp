@@ -123,6 +123,8 @@ sr::DevScene dev_scene(const sr_scene* s) {
     d.rdepth = s->ref.tree_depth;
     d.bnodes = (const sr::BvhNode*)s->d_bnodes.p; d.btris = (const sr::Rec128*)s->d_btris.p; d.bdepth = s->bvh.depth;
     d.bslab = (const sr::TriSlab*)s->d_bslab.p;
+    d.bnode_bits = 1;
+    while ((1ull << d.bnode_bits) < s->bvh.nodes.size() + 1 && d.bnode_bits < 26) d.bnode_bits++;
     d.root = s->root;
     return d;
 }

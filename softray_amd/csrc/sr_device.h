@@ -23,6 +23,7 @@ struct DevScene {
     const Rec128*  btris;       // triangle records gathered in leaf order (aux = TriangleIndex)
     const TriSlab* bslab;       // fp32 shaft-prefilter records, same order as btris
     int32_t        bdepth;
+    int32_t        bnode_bits;  // bits needed for a BVH node index (stack words pack node | bound)
     RootBox        root;
 };
 

@@ -167,7 +167,7 @@ const char* kernel_name(int id) {
 
 static int stack_levels_for(const DevScene& sc, int mode) {
     if (mode == MODE_REF) return sc.rdepth + 2;
-    if (mode == MODE_BVH) return 2 * (sc.bdepth + 2);
+    if (mode == MODE_BVH) return sc.bdepth + 2;
     return 1;
 }
 

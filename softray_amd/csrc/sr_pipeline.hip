@@ -378,6 +378,8 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
         const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
         const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
+        const int nbits = sc.bnode_bits, qmax = (1 << (31 - nbits)) - 1;   // stack word = node | quantised u bound
+        const float qinv = 1.0f / (float)qmax * 1.000001f;
         int32_t* out = cand + (size_t)slot_i * cap;
         int count = -skip;             // candidates with ordinal < skip were handled by an earlier round
         bool truncated = false;
@@ -422,15 +424,18 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
             const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
             if (i0 && i1) {
                 const bool first0 = a0 <= a1;                              // the child nearest to the surface point first
-                st.put(sp++, first0 ? n.c1 : n.c0);
-                st.put(sp++, __float_as_int(first0 ? b1 : b0));
+                // one stack word: node index | u upper bound quantised UP to qbits bits (conservative)
+                const float bu = fminf(1.0f, fmaxf(0.0f, first0 ? b1 : b0));
+                const int qu = min(qmax, (int)(bu * (float)qmax) + 1);
+                st.put(sp++, (first0 ? n.c1 : n.c0) | (qu << nbits));
                 ni = first0 ? n.c0 : n.c1; nu = first0 ? b0 : b1;
             } else if (i0) { ni = n.c0; nu = b0; }
             else if (i1) { ni = n.c1; nu = b1; }
             else {
                 if (sp == 0) break;
-                nu = __int_as_float(st.get(--sp));
-                ni = st.get(--sp);
+                const int w = st.get(--sp);
+                ni = w & ((1 << nbits) - 1);
+                nu = (float)((unsigned)w >> nbits) * qinv;
             }
         }
         cand_count[slot_i] = (unsigned)max(count, 0) | (truncated ? kTruncated : 0u);
@@ -633,7 +638,7 @@ __global__ __launch_bounds__(256) void k_resolve(FrameConst fc, const int32_t* _
 // --------------------------------------------------------------------------------------------------
 static int pipe_stack_levels(const DevScene& sc, int mode) {
     if (mode == MODE_REF) return sc.rdepth + 2;
-    if (mode == MODE_BVH) return 2 * (sc.bdepth + 2);
+    if (mode == MODE_BVH) return sc.bdepth + 2;
     return 1;
 }
 

@@ -304,22 +304,15 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
         if (i0 && i1) {
             bool first0 = t0 <= t1;
             int32_t farC = first0 ? n.c1 : n.c0;
-            float farT = first0 ? t1 : t0;
-            st.put(sp++, farC);
-            st.put(sp++, __float_as_int(farT));
+            st.put(sp++, farC);                               // the far child is re-tested against tlim when it is popped
             ni = first0 ? n.c0 : n.c1;
         } else if (i0) {
             ni = n.c0;
         } else if (i1) {
             ni = n.c1;
         } else {
-            bool found = false;
-            while (sp > 0) {
-                float ft = __int_as_float(st.get(--sp));
-                int32_t cand = st.get(--sp);
-                if (ft <= tlim) { ni = cand; found = true; break; }
-            }
-            if (!found) break;
+            if (sp == 0) break;
+            ni = st.get(--sp);
         }
     }
     if (ANY || bestK < 0) return false;
