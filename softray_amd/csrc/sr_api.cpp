@@ -272,10 +272,8 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             round_items[r] = r == 0 ? (unsigned)band_samples : (unsigned)std::max<long long>(1024, (long long)round_items[r - 1] / (r == 1 ? 8 : 4));
             SR_HIP(s->d_rcount[r].reserve((size_t)round_items[r] * 4));
             SR_HIP(s->d_rcand[r].reserve((size_t)round_items[r] * sr::pipeline_round_cap(r) * 4));
-            if (r > 0) {
-                SR_HIP(s->d_rlist[r].reserve((size_t)round_items[r] * 4));
-                SR_HIP(s->d_rstate[r].reserve((size_t)round_items[r] * sr::pipeline_round_state_bytes()));
-            }
+            SR_HIP(s->d_rlist[r].reserve((size_t)round_items[r] * 4));     // round 0: the hits k_shaft left undecided
+            if (r > 0) SR_HIP(s->d_rstate[r].reserve((size_t)round_items[r] * sr::pipeline_round_state_bytes()));
         }
     }
     if (n2 > 1) SR_HIP(s->d_samples.reserve((size_t)band_samples * 4));
@@ -298,7 +296,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     P.fallback = shaft ? (unsigned int*)s->d_fallback.p : nullptr;
     for (int r = 0; r < sr::kShaftRounds; ++r) {
         P.round_items[r] = round_items[r];
-        P.round_list[r] = (shaft && r > 0) ? (unsigned int*)s->d_rlist[r].p : nullptr;
+        P.round_list[r] = shaft ? (unsigned int*)s->d_rlist[r].p : nullptr;
         P.round_state[r] = (shaft && r > 0) ? s->d_rstate[r].p : nullptr;
         P.round_cand_count[r] = shaft ? (unsigned int*)s->d_rcount[r].p : nullptr;
         P.round_cand[r] = shaft ? (int32_t*)s->d_rcand[r].p : nullptr;

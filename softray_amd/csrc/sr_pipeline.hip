@@ -331,13 +331,24 @@ __device__ __forceinline__ void clip_ge(const Lin& l, float bound, float& ua, fl
     else if (l.sgn < 0) ub = fminf(ub, v);
     else if (!(l.f0 >= bound)) ub = -1e30f;
 }
-__device__ __forceinline__ bool shaft_touches(const TriSlab s, float ex, float ey, float ez, float dx, float dy, float dz,
-                                              float ua, float ub, float R, float pad) {
+// returns 0: no sample ray can touch the triangle; 1: candidate; 2: UMBRA -- every possible sample ray crosses this
+// triangle well inside it, in front of the surface point: the hit point is fully shadowed whatever the samples are.
+//
+// Umbra argument (all margins are orders of magnitude above the fp32 evaluation error): a sample ray deviates from the
+// centre ray by at most R u at parameter u.  With g(u) = n.C(u) - d = n0 + u n1 and n1 > R (front-facing for every
+// sample direction), a sample crosses the plane at some u_i with |g(u_i)| <= R u_i, i.e. u_i in [ulo, uhi] =
+// [-n0/(n1+R), -n0/(n1-R)].  Its crossing point is within R uhi of C(u_i), so edge function k there is at least
+// min over [ulo, uhi] of (k0 + u k1) - R uhi.  If that exceeds the margin for the three edges, the crossing lies
+// strictly inside the triangle (hence inside the root box), at 0 < t < 1: Triangle.IntersectRay accepts it and
+// rayFrac <= 1.0 for every sample (ShadowMethod.cs:170), so rayEscapeCount = 0.
+__device__ __forceinline__ int shaft_touches(const TriSlab s, float ex, float ey, float ez, float dx, float dy, float dz,
+                                             float ua, float ub, float R, float pad, float ext, float hbx, float hby, float hbz) {
     const float n0 = s.n[0] * ex + s.n[1] * ey + s.n[2] * ez - s.d, n1 = s.n[0] * dx + s.n[1] * dy + s.n[2] * dz;
+    const float p0 = s.m1[0] * ex + s.m1[1] * ey + s.m1[2] * ez - s.c1, p1 = s.m1[0] * dx + s.m1[1] * dy + s.m1[2] * dz;
+    const float q0 = s.m2[0] * ex + s.m2[1] * ey + s.m2[2] * ez - s.c2, q1 = s.m2[0] * dx + s.m2[1] * dy + s.m2[2] * dz;
+    const float r0 = s.m3[0] * ex + s.m3[1] * ey + s.m3[2] * ez - s.c3, r1 = s.m3[0] * dx + s.m3[1] * dy + s.m3[2] * dz;
     const Lin ln = make_lin(n0, n1), lm = make_lin(-n0, -n1);
-    const Lin l1 = make_lin(s.m1[0] * ex + s.m1[1] * ey + s.m1[2] * ez - s.c1, s.m1[0] * dx + s.m1[1] * dy + s.m1[2] * dz);
-    const Lin l2 = make_lin(s.m2[0] * ex + s.m2[1] * ey + s.m2[2] * ez - s.c2, s.m2[0] * dx + s.m2[1] * dy + s.m2[2] * dz);
-    const Lin l3 = make_lin(s.m3[0] * ex + s.m3[1] * ey + s.m3[2] * ez - s.c3, s.m3[0] * dx + s.m3[1] * dy + s.m3[2] * dz);
+    const Lin l1 = make_lin(p0, p1), l2 = make_lin(q0, q1), l3 = make_lin(r0, r1);
     // the shaft radius at the far end of the current interval bounds the deviation; clipping shrinks the interval,
     // which shrinks the radius: one refinement
 #pragma unroll
@@ -348,9 +359,25 @@ __device__ __forceinline__ bool shaft_touches(const TriSlab s, float ex, float e
         clip_ge(l1, -rho, ua, ub);
         clip_ge(l2, -rho, ua, ub);
         clip_ge(l3, -rho, ua, ub);
-        if (!(ua <= ub + 1e-6f)) return false;
+        if (!(ua <= ub + 1e-6f)) return 0;
     }
-    return true;
+    // ---- umbra test ----
+    const float Rm = R * 1.001f;
+    if (n1 > 2.0f * Rm && n0 < 0.0f) {                          // front-facing for all samples, plane between light and surface point
+        const float ulo = -n0 / (n1 + Rm), uhi = -n0 / (n1 - Rm);
+        if (ulo > 2e-3f && uhi < 0.5f) {
+            const float margin = Rm * uhi + 1e-3f * ext;
+            const float e1 = fminf(p0 + ulo * p1, p0 + uhi * p1), e2 = fminf(q0 + ulo * q1, q0 + uhi * q1), e3 = fminf(r0 + ulo * r1, r0 + uhi * r1);
+            if (e1 > margin && e2 > margin && e3 > margin) {
+                // the crossing region must also be inside the root box (hits outside it are no hits: SpatialSubdivision.cs:652)
+                const float ax = ex + ulo * dx, ay = ey + ulo * dy, az = ez + ulo * dz;
+                const float bx = ex + uhi * dx, by = ey + uhi * dy, bz = ez + uhi * dz;
+                const float m = margin;
+                if (fmaxf(fabsf(ax), fabsf(bx)) + m < hbx && fmaxf(fabsf(ay), fabsf(by)) + m < hby && fmaxf(fabsf(az), fabsf(bz)) + m < hbz) return 2;
+            }
+        }
+    }
+    return 1;
 }
 
 template <bool STATS>
@@ -358,7 +385,8 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                                                const unsigned int* __restrict__ hit_count, unsigned int count_cap,
                                                const unsigned int* __restrict__ index_list, int skip, int cap,
                                                unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
-                                               unsigned long long* stats) {
+                                               uint32_t* __restrict__ samples, unsigned int* __restrict__ work_count,
+                                               unsigned int* __restrict__ work_list, unsigned long long* stats, unsigned int* dbg) {
     const int tid = threadIdx.x, lane = tid & 63;
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
     const unsigned int total = min(*hit_count, count_cap);
@@ -378,11 +406,12 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
         const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
         const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
+        const float hbx = 0.5f * (float)(sc.root.max[0] - sc.root.min[0]), hby = 0.5f * (float)(sc.root.max[1] - sc.root.min[1]), hbz = 0.5f * (float)(sc.root.max[2] - sc.root.min[2]);
         const int nbits = sc.bnode_bits, qmax = (1 << (31 - nbits)) - 1;   // stack word = node | quantised u bound
         const float qinv = 1.0f / (float)qmax * 1.000001f;
         int32_t* out = cand + (size_t)slot_i * cap;
         int count = -skip;             // candidates with ordinal < skip were handled by an earlier round
-        bool truncated = false;
+        bool truncated = false, umbra = false;
         int sp = 0;
         int32_t ni = 0;
         float nu = 1.0f;               // upper bound of u (distance from the surface end) inside the current subtree
@@ -412,14 +441,16 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                         const float ua = use0 ? a0 : a1, ub = use0 ? b0 : b1;
                         leaves++;
                         for (int q = 0; q < cnt; ++q) {
-                            if (shaft_touches(sc.bslab[first + q], ex, ey, ez, dx, dy, dz, ua, ub, R, pad_tri)) {
+                            const int touch = shaft_touches(sc.bslab[first + q], ex, ey, ez, dx, dy, dz, ua, ub, R, pad_tri, ext, hbx, hby, hbz);
+                            if (touch == 2) umbra = true;
+                            if (touch) {
                                 if (count < cap) { if (count >= 0) out[count] = first + q; count++; }
                                 else truncated = true;
                             }
                         }
                     }
                 }
-                if (truncated) break;
+                if (truncated || umbra) break;
             }
             const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
             if (i0 && i1) {
@@ -438,7 +469,15 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                 nu = (float)((unsigned)w >> nbits) * qinv;
             }
         }
-        cand_count[slot_i] = (unsigned)max(count, 0) | (truncated ? kTruncated : 0u);
+        if (umbra) {
+            // fully shadowed: rayEscapeCount = 0 -> (byte)(0.0 * 255) = 0 -> ModulatePackedColor(color, 0) = opaque black
+            samples[rec.sample] = modulate(samples[rec.sample], 0u);
+            cand_count[slot_i] = 0u;
+            if (fc.debug == 7) atomicAdd(dbg + 7, 1u);
+        } else {
+            cand_count[slot_i] = (unsigned)max(count, 0) | (truncated ? kTruncated : 0u);
+            if (work_list) work_list[atomicAdd(work_count, 1u)] = h;      // the compiler aggregates this per wavefront
+        }
     }
     if (STATS) {
         uint32_t a = wave_sum(nodes), b = wave_sum(leaves);
@@ -455,7 +494,7 @@ template <bool EXTRA, bool STATS>
 __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
                                                      const HitRec* __restrict__ hits, const unsigned int* __restrict__ hit_count,
                                                      unsigned int count_cap, const unsigned int* __restrict__ index_list,
-                                                     const RoundState* __restrict__ state_in, int cap,
+                                                     const RoundState* __restrict__ state_in, int cap, int lists_by_hit,
                                                      const unsigned int* __restrict__ cand_count, const int32_t* __restrict__ cand,
                                                      unsigned int* __restrict__ next_count, unsigned int next_cap,
                                                      unsigned int* __restrict__ next_list, RoundState* __restrict__ state_out,
@@ -485,10 +524,11 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
         const unsigned int h = index_list ? index_list[slot_i] : slot_i;
         const HitRec rec = hits[h];
         const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
-        const unsigned int cc = cand_count[slot_i];
+        const size_t li = lists_by_hit ? (size_t)h : (size_t)slot_i;   // round 0: lists are stored per hit, later rounds per item
+        const unsigned int cc = cand_count[li];
         const int ntri = (int)(cc & 0xffffu);
         const bool truncated = (cc & kTruncated) != 0;
-        const int32_t* list = cand + (size_t)slot_i * cap;
+        const int32_t* list = cand + li * cap;
         const bool work = ntri > 0 || truncated;      // an empty, complete list: every sample escapes, no clipping needed
         SampleRay ray[kPacketSlots];
         bool alive[kPacketSlots], escaped[kPacketSlots];
@@ -691,8 +731,9 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
         return hipSuccess;
     }
-    // counters: [0] hits  [1] k_shadow head  [2..] items entering round 1, 2, ..  [2+R-1] fallback count  [2+R] fallback head
+    // counters: [0] hits  [1] k_shadow head  [2..] items entering round 1, 2, ..  [2+R-1] fallback count  [6] round-0 work items
     unsigned int* fb_count = L.counters + 2 + (kShaftRounds - 1);
+    unsigned int* work0 = L.counters + 6;
     int skip = 0;
     for (int round = 0; round < kShaftRounds; ++round) {
         const bool first = round == 0, last = round == kShaftRounds - 1;
@@ -708,8 +749,10 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         {
             size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
             unsigned blocks = (unsigned)((max_items + 255) / 256);
-            if (L.stats) hipLaunchKernelGGL((k_shaft<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, L.round_cand_count[round], L.round_cand[round], L.stats);
-            else hipLaunchKernelGGL((k_shaft<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, L.round_cand_count[round], L.round_cand[round], L.stats);
+            unsigned int* wc = first ? work0 : nullptr;
+            unsigned int* wl = first ? L.round_list[0] : nullptr;
+            if (L.stats) hipLaunchKernelGGL((k_shaft<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, L.round_cand_count[round], L.round_cand[round], samples, wc, wl, L.stats, L.counters);
+            else hipLaunchKernelGGL((k_shaft<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, L.round_cand_count[round], L.round_cand[round], samples, wc, wl, L.stats, L.counters);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
@@ -725,8 +768,11 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
             const unsigned next_cap = last ? 0u : L.round_items[round + 1];
             unsigned int* next_list = last ? nullptr : L.round_list[round + 1];
             RoundState* st_out = last ? nullptr : (RoundState*)L.round_state[round + 1];
-            if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, count_ptr, count_cap, ilist, st_in, cap, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, samples, L.stats);
-            else hipLaunchKernelGGL((k_shadow_test<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, count_ptr, count_cap, ilist, st_in, cap, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, samples, L.stats);
+            // round 0 iterates the compacted list of hits that k_shaft could not decide by itself
+            const unsigned int* t_count = first ? work0 : count_ptr;
+            const unsigned int* t_list = first ? L.round_list[0] : ilist;
+            if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, samples, L.stats);
+            else hipLaunchKernelGGL((k_shadow_test<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, samples, L.stats);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
