@@ -152,7 +152,7 @@ int  sr_tree_stats(const sr_scene*, int32_t out[4]);
 int  sr_render(sr_scene*, const sr_frame*, int32_t* pixels, uint64_t stats[4]);
 /* Same, but `d_pixels` is DEVICE memory on the scene's device (e.g. a torch tensor's data_ptr) and the
  * work is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream) without host sync. */
-int  sr_render_device(sr_scene*, const sr_frame*, void* d_pixels, void* hip_stream, uint64_t* d_stats /* device uint64[8] (see sr_last_ray_stats) or NULL */);
+int  sr_render_device(sr_scene*, const sr_frame*, void* d_pixels, void* hip_stream, uint64_t* d_stats /* device uint64[12] (see sr_last_ray_stats) or NULL */);
 /* number of int32 pixels sr_render writes for this frame (W*H, or the compact strip size) */
 int64_t sr_frame_pixel_count(const sr_frame*);
 
@@ -188,10 +188,12 @@ typedef struct { const char* name; float ms; int32_t launches; } sr_kernel_time;
 void sr_reset_kernel_times(sr_scene*);
 int  sr_kernel_times(sr_scene*, sr_kernel_time* out, int32_t cap);
 
-/* Ray statistics of the last sr_render(..., stats != NULL): primary {rays, triangle/primitive tests, nodes
- * visited, leaf nodes visited} followed by the same four for secondary (shadow) rays.  These are the
- * counters the roofline's algorithmic bytes are priced from (DESIGN.md "Measurement"). */
-int  sr_last_ray_stats(const sr_scene*, uint64_t out[8]);
+/* Ray statistics of the last sr_render(..., stats != NULL): [0..3] primary rays {rays, triangle/primitive tests, nodes
+ * visited, leaf nodes visited}; [4..7] the same for secondary (shadow) rays -- on the shaft path [6],[7] are the shaft
+ * walks' nodes / leaves; [8] triangle records staged through LDS by k_shadow_test, [9] hit points it processed,
+ * [10] fp32 slab records read by k_shaft, [11] hit points it walked.  These are the counters the roofline's
+ * algorithmic bytes are priced from (DESIGN.md "Measurement"). */
+int  sr_last_ray_stats(const sr_scene*, uint64_t out[12]);
 
 /* Seeded synthetic triangle soup = SpatialSubdivisionTests.MakeRandomTriangles
  * (Engine3D-Tests/Raytrace/SpatialSubdivisionTests.cs:397-411) driven by the System.Random port: per triangle

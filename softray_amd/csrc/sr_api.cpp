@@ -79,7 +79,7 @@ struct sr_scene {
     // kernel timing: one HIP event pair per launch, accumulated until sr_reset_kernel_times()
     std::vector<hipEvent_t> ev[sr::K_COUNT];       // [2*i] start, [2*i+1] stop
     int  ev_used[sr::K_COUNT] = {};
-    uint64_t last_stats[8] = {};
+    uint64_t last_stats[12] = {};
 };
 
 namespace {
@@ -446,7 +446,7 @@ int sr_render_device(sr_scene* s, const sr_frame* f, void* d_pixels, void* hip_s
     if ((rc = check_mode(s, f->trace_mode))) return rc;
     if ((rc = use_device(s))) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
-    if (d_stats) SR_HIP(hipMemsetAsync(d_stats, 0, 8 * sizeof(uint64_t), stream));
+    if (d_stats) SR_HIP(hipMemsetAsync(d_stats, 0, 12 * sizeof(uint64_t), stream));
     return render_common(s, f, (uint32_t*)d_pixels, stream, (unsigned long long*)d_stats);
 }
 
@@ -460,8 +460,8 @@ int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]
     SR_HIP(s->d_pixels.reserve((size_t)count * 4));
     unsigned long long* d_stats = nullptr;
     if (stats) {
-        SR_HIP(s->d_stats.reserve(8 * sizeof(uint64_t)));
-        SR_HIP(hipMemsetAsync(s->d_stats.p, 0, 8 * sizeof(uint64_t), nullptr));
+        SR_HIP(s->d_stats.reserve(12 * sizeof(uint64_t)));
+        SR_HIP(hipMemsetAsync(s->d_stats.p, 0, 12 * sizeof(uint64_t), nullptr));
         d_stats = (unsigned long long*)s->d_stats.p;
     }
     if ((rc = render_common(s, f, (uint32_t*)s->d_pixels.p, nullptr, d_stats))) return rc;
@@ -477,7 +477,7 @@ int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]
         SR_HIP(hipMemcpy(pixels + off, (const int32_t*)s->d_pixels.p + off, n * 4, hipMemcpyDeviceToHost));
     }
     if (stats) {
-        SR_HIP(hipMemcpy(s->last_stats, s->d_stats.p, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        SR_HIP(hipMemcpy(s->last_stats, s->d_stats.p, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost));
         std::memcpy(stats, s->last_stats, 4 * sizeof(uint64_t));
     }
     return SR_OK;
@@ -538,7 +538,7 @@ int sr_get_triangles(const sr_scene* s, double* v9, uint32_t* argb, double box_m
     return SR_OK;
 }
 
-int sr_last_ray_stats(const sr_scene* s, uint64_t out[8]) {
+int sr_last_ray_stats(const sr_scene* s, uint64_t out[12]) {
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
     std::memcpy(out, s->last_stats, sizeof(s->last_stats));
     return SR_OK;

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
     const unsigned int total = min(*hit_count, count_cap);
     const unsigned int slot_i = blockIdx.x * 256u + (unsigned)tid;       // list slot: the hit itself, or an entry of index_list
-    uint32_t nodes = 0, leaves = 0;
+    uint32_t nodes = 0, leaves = 0, slabs = 0;
     if (slot_i < total) {
         const unsigned int h = index_list ? index_list[slot_i] : slot_i;
         const HitRec rec = hits[h];
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                         const int first = use0 ? n.c0 : n.c1, cnt = use0 ? n.n0 : n.n1;
                         const float ua = use0 ? a0 : a1, ub = use0 ? b0 : b1;
                         leaves++;
+                        slabs += (uint32_t)cnt;
                         for (int q = 0; q < cnt; ++q) {
                             const int touch = shaft_touches(sc.bslab[first + q], ex, ey, ez, dx, dy, dz, ua, ub, R, pad_tri, ext, hbx, hby, hbz);
                             if (touch == 2) umbra = true;
@@ -480,8 +481,11 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         }
     }
     if (STATS) {
-        uint32_t a = wave_sum(nodes), b = wave_sum(leaves);
-        if (lane == 0) { atomicAdd(&stats[6], (unsigned long long)a); atomicAdd(&stats[7], (unsigned long long)b); }
+        uint32_t a = wave_sum(nodes), b = wave_sum(leaves), c2 = wave_sum(slabs), d2 = wave_sum(slot_i < total ? 1u : 0u);
+        if (lane == 0) {
+            atomicAdd(&stats[6], (unsigned long long)a); atomicAdd(&stats[7], (unsigned long long)b);
+            atomicAdd(&stats[10], (unsigned long long)c2); atomicAdd(&stats[11], (unsigned long long)d2);
+        }
     }
 }
 
@@ -523,6 +527,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
     for (unsigned int slot_i = blockIdx.x * 4u + (unsigned)wave; slot_i < total; slot_i += nwaves) {
         const unsigned int h = index_list ? index_list[slot_i] : slot_i;
         const HitRec rec = hits[h];
+        sec.leaves++;
         const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
         const size_t li = lists_by_hit ? (size_t)h : (size_t)slot_i;   // round 0: lists are stored per hit, later rounds per item
         const unsigned int cc = cand_count[li];
@@ -553,6 +558,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
         bool have = __any(alive[0] || alive[1]);
         for (int base = 0; base < ntri && have; base += kRecordsPerPass) {
             const int npass = min(kRecordsPerPass, ntri - base);
+            sec.nodes += (uint32_t)npass;
             // ---- stage up to 16 records (2 KB) through LDS: lane -> (record slot, 16-byte piece), coalesced dwordx4 ----
 #pragma unroll
             for (int pass = 0; pass < kRecordsPerPass / 8; ++pass) {
@@ -601,7 +607,11 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
     }
     if (STATS) {
         uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom);
-        if (lane == 0) { atomicAdd(&stats[4], (unsigned long long)a); atomicAdd(&stats[5], (unsigned long long)b); }
+        if (lane == 0) {
+            atomicAdd(&stats[4], (unsigned long long)a); atomicAdd(&stats[5], (unsigned long long)b);
+            atomicAdd(&stats[8], (unsigned long long)sec.nodes);          // wave-level: records staged through LDS
+            atomicAdd(&stats[9], (unsigned long long)sec.leaves);         // wave-level: hit points processed
+        }
     }
 }
 
