@@ -524,17 +524,57 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
     }
     Ctr sec = {0, 0, 0, 0};
     const unsigned int nwaves = gridDim.x * 4u;
-    for (unsigned int slot_i = blockIdx.x * 4u + (unsigned)wave; slot_i < total; slot_i += nwaves) {
-        const unsigned int h = index_list ? index_list[slot_i] : slot_i;
-        const HitRec rec = hits[h];
+    const unsigned int s0 = blockIdx.x * 4u + (unsigned)wave;
+    const int pre = min(cap, 64);                  // list entries kept in registers: lane l holds entry l
+    // software pipeline over this wave's items: the hit index is fetched two items ahead, the hit record / list
+    // head one item ahead, the first chunk's triangle records before the (long) per-sample clip of the current item
+    unsigned int h_cur = 0, h_nxt = 0;
+    HitRec rec_cur;
+    unsigned int cc_cur = 0;
+    int32_t ent_cur = 0;
+    if (s0 < total) {
+        h_cur = index_list ? index_list[s0] : s0;
+        rec_cur = hits[h_cur];
+        const size_t li0 = lists_by_hit ? (size_t)h_cur : (size_t)s0;
+        cc_cur = cand_count[li0];
+        ent_cur = lane < pre ? cand[li0 * cap + lane] : 0;
+    }
+    if (s0 + nwaves < total) h_nxt = index_list ? index_list[s0 + nwaves] : s0 + nwaves;
+    for (unsigned int slot_i = s0; slot_i < total; slot_i += nwaves) {
+        const unsigned int h = h_cur;
+        const HitRec rec = rec_cur;
+        const unsigned int cc = cc_cur;
+        const int32_t ent = ent_cur;
         sec.leaves++;
         const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
         const size_t li = lists_by_hit ? (size_t)h : (size_t)slot_i;   // round 0: lists are stored per hit, later rounds per item
-        const unsigned int cc = cand_count[li];
         const int ntri = (int)(cc & 0xffffu);
         const bool truncated = (cc & kTruncated) != 0;
         const int32_t* list = cand + li * cap;
         const bool work = ntri > 0 || truncated;      // an empty, complete list: every sample escapes, no clipping needed
+        // ---- (a) issue the record loads of the first chunk: lane -> (record slot, 16-byte piece), coalesced dwordx4 ----
+        uint4 r0[kRecordsPerPass / 8];
+        const int n0 = min(kRecordsPerPass, ntri);
+#pragma unroll
+        for (int pass = 0; pass < kRecordsPerPass / 8; ++pass) {
+            const int slot = pass * 8 + (lane >> 3);
+            const int32_t e = __shfl(ent, slot, 64);
+            r0[pass] = make_uint4(0, 0, 0, 0);
+            if (slot < n0) r0[pass] = reinterpret_cast<const uint4*>(&sc.btris[e])[lane & 7];
+        }
+        // ---- (b) prefetch the next item ----
+        {
+            const unsigned int sn = slot_i + nwaves, snn = sn + nwaves;
+            h_cur = h_nxt;
+            if (sn < total) {
+                rec_cur = hits[h_cur];
+                const size_t lin = lists_by_hit ? (size_t)h_cur : (size_t)sn;
+                cc_cur = cand_count[lin];
+                ent_cur = lane < pre ? cand[lin * cap + lane] : 0;
+            }
+            if (snn < total) h_nxt = index_list ? index_list[snn] : snn;
+        }
+        // ---- (c) per-sample rays: clip + rayFracOffset ----
         SampleRay ray[kPacketSlots];
         bool alive[kPacketSlots], escaped[kPacketSlots];
 #pragma unroll
@@ -559,15 +599,23 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
         for (int base = 0; base < ntri && have; base += kRecordsPerPass) {
             const int npass = min(kRecordsPerPass, ntri - base);
             sec.nodes += (uint32_t)npass;
-            // ---- stage up to 16 records (2 KB) through LDS: lane -> (record slot, 16-byte piece), coalesced dwordx4 ----
+            // ---- (d) stage up to 16 records (2 KB) through LDS ----
 #pragma unroll
             for (int pass = 0; pass < kRecordsPerPass / 8; ++pass) {
                 const int slot = pass * 8 + (lane >> 3);
-                if (slot < npass) wrec[slot * 8 + (lane & 7)] = reinterpret_cast<const uint4*>(&sc.btris[list[base + slot]])[lane & 7];
+                if (base == 0) {
+                    if (slot < npass) wrec[slot * 8 + (lane & 7)] = r0[pass];
+                } else {
+                    const int32_t es = __shfl(ent, (base + slot) & 63, 64);   // all lanes take part in the shuffle
+                    if (slot < npass) {
+                        const int32_t e = (base + kRecordsPerPass <= pre) ? es : list[base + slot];
+                        wrec[slot * 8 + (lane & 7)] = reinterpret_cast<const uint4*>(&sc.btris[e])[lane & 7];
+                    }
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            // ---- every lane tests its undecided samples against the staged records (exact FP64) ----
+            // ---- (e) every lane tests its undecided samples against the staged records (exact FP64) ----
             for (int k = 0; k < npass && have; ++k) {
                 const double* p = wrecd + (size_t)k * 16;
 #pragma unroll
