@@ -258,7 +258,7 @@ def main():
                                  "resident and the kernels are FP64-issue / latency bound, not HBM bound; per_ray_touch is SURVEY 8d's "
                                  "per-lane figure (4 B + 64 B/node + 128 B/triangle test per ray)"},
             "kernels_ms": {k: v[0] for k, v in kt.items()}, "kernel_launches": {k: v[1] for k, v in kt.items()},
-            "pipeline_counters_last_band": g.debug_counters(),
+            "pipeline_counters_last_band": g.debug_counters(), "device_counters": [float(x) for x in rs],
             "build_s": build_s, "d2h_ms": d2h_ms,
         }
         if world == 1 and not args.no_cpu_baseline:

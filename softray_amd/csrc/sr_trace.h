@@ -266,53 +266,59 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
     int32_t bestIdx = 0x7fffffff, bestK = -1;
     D3 bestPos = mk(0, 0, 0);
 
+    // "while-while" traversal: a lane first walks inner nodes until it owns a pending leaf (or is finished), and only
+    // then the (long, FP64) triangle tests run -- so a wavefront executes the leaf code with most lanes busy instead of
+    // once per node step for the few lanes that happen to be at a leaf.
     int sp = 0;
-    int32_t ni = 0;
+    int32_t ni = 0;                  // next inner node, -1: walk finished
+    int32_t leafA = -1, leafB = -1;  // pending leaves: first record | count << 28
     for (;;) {
-        const BvhNode n = sc.bnodes[ni];
-        c.nodes++;
-        float t0, x0, t1, x1;
-        slab(n.lo0, n.hi0, ox, oy, oz, ix, iy, iz, t0, x0);
-        slab(n.lo1, n.hi1, ox, oy, oz, ix, iy, iz, t1, x1);
-        bool h0 = n.n0 >= 0 && t0 <= x0 && x0 >= 0.0f && t0 <= tlim;
-        bool h1 = n.n1 >= 0 && t1 <= x1 && x1 >= 0.0f && t1 <= tlim;
-#pragma unroll
-        for (int side = 0; side < 2; ++side) {
-            bool h = side ? h1 : h0;
-            int32_t cn = side ? n.n1 : n.n0, cc = side ? n.c1 : n.c0;
-            if (h && cn > 0) {
-                c.leaves++;
-                for (int k = cc; k < cc + cn; ++k) {
-                    const Rec128* r = &sc.btris[k];
-                    double t; D3 pos;
-                    c.geom++;
-                    if (tri_hit(r->p, s, d, t, pos) && inside(sc.root.lo, sc.root.hi, pos)) {
-                        if (ANY) {
-                            if (t + offset <= 1.0) { out.t = t + offset; out.tri = k; return true; }   // out.tri = record position: the caller's blocker cache
-                        } else {
-                            int32_t idx = r->aux;
-                            if (t < best || (t == best && idx < bestIdx)) {
-                                best = t; bestIdx = idx; bestK = k; bestPos = pos;
-                                tlim = (float)best * kInfl + 1e-30f;
-                            }
+        while (ni >= 0 && leafA < 0) {
+            const BvhNode n = sc.bnodes[ni];
+            c.nodes++;
+            float t0, x0, t1, x1;
+            slab(n.lo0, n.hi0, ox, oy, oz, ix, iy, iz, t0, x0);
+            slab(n.lo1, n.hi1, ox, oy, oz, ix, iy, iz, t1, x1);
+            const bool h0 = n.n0 >= 0 && t0 <= x0 && x0 >= 0.0f && t0 <= tlim;
+            const bool h1 = n.n1 >= 0 && t1 <= x1 && x1 >= 0.0f && t1 <= tlim;
+            const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
+            if (l0 && l1) {                                   // nearer leaf first
+                const bool first0 = t0 <= t1;
+                leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << 28);
+                leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << 28);
+            } else if (l0) leafA = n.c0 | (n.n0 << 28);
+            else if (l1) leafA = n.c1 | (n.n1 << 28);
+            const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
+            if (i0 && i1) {
+                const bool first0 = t0 <= t1;
+                st.put(sp++, first0 ? n.c1 : n.c0);           // the far child is re-tested against tlim when it is popped
+                ni = first0 ? n.c0 : n.c1;
+            } else if (i0) ni = n.c0;
+            else if (i1) ni = n.c1;
+            else ni = (sp > 0) ? st.get(--sp) : -1;
+        }
+        if (leafA < 0) break;
+        while (leafA >= 0) {
+            const int32_t first = leafA & 0x0fffffff, cn = (leafA >> 28) & 7;
+            leafA = leafB;
+            leafB = -1;
+            c.leaves++;
+            for (int k = first; k < first + cn; ++k) {
+                const Rec128* r = &sc.btris[k];
+                double t; D3 pos;
+                c.geom++;
+                if (tri_hit(r->p, s, d, t, pos) && inside(sc.root.lo, sc.root.hi, pos)) {
+                    if (ANY) {
+                        if (t + offset <= 1.0) { out.t = t + offset; out.tri = k; return true; }   // out.tri = record position: the caller's blocker cache
+                    } else {
+                        const int32_t idx = r->aux;
+                        if (t < best || (t == best && idx < bestIdx)) {
+                            best = t; bestIdx = idx; bestK = k; bestPos = pos;
+                            tlim = (float)best * kInfl + 1e-30f;
                         }
                     }
                 }
             }
-        }
-        bool i0 = h0 && n.n0 == 0 && t0 <= tlim, i1 = h1 && n.n1 == 0 && t1 <= tlim;
-        if (i0 && i1) {
-            bool first0 = t0 <= t1;
-            int32_t farC = first0 ? n.c1 : n.c0;
-            st.put(sp++, farC);                               // the far child is re-tested against tlim when it is popped
-            ni = first0 ? n.c0 : n.c1;
-        } else if (i0) {
-            ni = n.c0;
-        } else if (i1) {
-            ni = n.c1;
-        } else {
-            if (sp == 0) break;
-            ni = st.get(--sp);
         }
     }
     if (ANY || bestK < 0) return false;
