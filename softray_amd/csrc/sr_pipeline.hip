@@ -37,7 +37,7 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 // k_primary
 // --------------------------------------------------------------------------------------------------
 template <int MODE, bool EXTRA, bool STATS>
-__global__ __launch_bounds__(256) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
+__global__ __launch_bounds__(256, 5) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
                                                  int row_count, uint32_t* __restrict__ samples, HitRec* __restrict__ hits,
                                                  unsigned int* __restrict__ hit_count, unsigned long long* stats) {
     const int tid = threadIdx.x;
@@ -415,60 +415,67 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         int sp = 0;
         int32_t ni = 0;
         float nu = 1.0f;               // upper bound of u (distance from the surface end) inside the current subtree
+        // while-while: walk inner nodes until this lane owns a pending leaf, then run the (per-triangle) slab filters
+        int32_t leafA = -1, leafB = -1;            // pending leaves: first record | count << 28
+        float laA = 0, lbA = 0, laB = 0, lbB = 0;  // their u-intervals
         for (;;) {
-            const BvhNode n = sc.bnodes[ni];
-            nodes++;
-            const float r = R * fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)) + pad;
-            float elo[3], ehi[3];
-            float a0, b0, a1, b1;      // child u-intervals [a, b]
+            while (ni >= 0 && leafA < 0) {
+                const BvhNode n = sc.bnodes[ni];
+                nodes++;
+                const float r = R * fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)) + pad;
+                float elo[3], ehi[3];
+                float a0, b0, a1, b1;      // child u-intervals [a, b]
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { elo[a] = n.lo0[a] - r; ehi[a] = n.hi0[a] + r; }
-            slab(elo, ehi, ex, ey, ez, ix, iy, iz, a0, b0);
+                for (int a = 0; a < 3; ++a) { elo[a] = n.lo0[a] - r; ehi[a] = n.hi0[a] + r; }
+                slab(elo, ehi, ex, ey, ez, ix, iy, iz, a0, b0);
 #pragma unroll
-            for (int a = 0; a < 3; ++a) { elo[a] = n.lo1[a] - r; ehi[a] = n.hi1[a] + r; }
-            slab(elo, ehi, ex, ey, ez, ix, iy, iz, a1, b1);
-            a0 = fmaxf(a0, umin); a1 = fmaxf(a1, umin);
-            b0 = fminf(b0, nu); b1 = fminf(b1, nu);
-            const bool h0 = n.n0 >= 0 && a0 <= b0, h1 = n.n1 >= 0 && a1 <= b1;
-            // leaves: the one nearest to the surface point first; each triangle is filtered with its fp32 slab record
-            const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
-            if (l0 || l1) {
-                const bool first0 = !l1 || (l0 && a0 <= a1);
-                for (int k = 0; k < 2; ++k) {
-                    const bool use0 = (k == 0) ? first0 : !first0;
-                    if (use0 ? l0 : l1) {
-                        const int first = use0 ? n.c0 : n.c1, cnt = use0 ? n.n0 : n.n1;
-                        const float ua = use0 ? a0 : a1, ub = use0 ? b0 : b1;
-                        leaves++;
-                        slabs += (uint32_t)cnt;
-                        for (int q = 0; q < cnt; ++q) {
-                            const int touch = shaft_touches(sc.bslab[first + q], ex, ey, ez, dx, dy, dz, ua, ub, R, pad_tri, ext, hbx, hby, hbz);
-                            if (touch == 2) umbra = true;
-                            if (touch) {
-                                if (count < cap) { if (count >= 0) out[count] = first + q; count++; }
-                                else truncated = true;
-                            }
-                        }
+                for (int a = 0; a < 3; ++a) { elo[a] = n.lo1[a] - r; ehi[a] = n.hi1[a] + r; }
+                slab(elo, ehi, ex, ey, ez, ix, iy, iz, a1, b1);
+                a0 = fmaxf(a0, umin); a1 = fmaxf(a1, umin);
+                b0 = fminf(b0, nu); b1 = fminf(b1, nu);
+                const bool h0 = n.n0 >= 0 && a0 <= b0, h1 = n.n1 >= 0 && a1 <= b1;
+                // leaves: the one nearest to the surface point first
+                const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
+                if (l0 && l1) {
+                    const bool first0 = a0 <= a1;
+                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << 28); laA = first0 ? a0 : a1; lbA = first0 ? b0 : b1;
+                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << 28); laB = first0 ? a1 : a0; lbB = first0 ? b1 : b0;
+                } else if (l0) { leafA = n.c0 | (n.n0 << 28); laA = a0; lbA = b0; }
+                else if (l1) { leafA = n.c1 | (n.n1 << 28); laA = a1; lbA = b1; }
+                const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
+                if (i0 && i1) {
+                    const bool first0 = a0 <= a1;                          // the child nearest to the surface point first
+                    // one stack word: node index | u upper bound quantised UP to qbits bits (conservative)
+                    const float bu = fminf(1.0f, fmaxf(0.0f, first0 ? b1 : b0));
+                    const int qu = min(qmax, (int)(bu * (float)qmax) + 1);
+                    st.put(sp++, (first0 ? n.c1 : n.c0) | (qu << nbits));
+                    ni = first0 ? n.c0 : n.c1; nu = first0 ? b0 : b1;
+                } else if (i0) { ni = n.c0; nu = b0; }
+                else if (i1) { ni = n.c1; nu = b1; }
+                else if (sp > 0) {
+                    const int w = st.get(--sp);
+                    ni = w & ((1 << nbits) - 1);
+                    nu = (float)((unsigned)w >> nbits) * qinv;
+                } else ni = -1;
+            }
+            if (leafA < 0) break;
+            while (leafA >= 0 && !truncated && !umbra) {
+                const int first = leafA & 0x0fffffff, cnt = (leafA >> 28) & 7;
+                const float ua = laA, ub = lbA;
+                leafA = leafB; laA = laB; lbA = lbB;
+                leafB = -1;
+                leaves++;
+                slabs += (uint32_t)cnt;
+                for (int q = 0; q < cnt; ++q) {
+                    const int touch = shaft_touches(sc.bslab[first + q], ex, ey, ez, dx, dy, dz, ua, ub, R, pad_tri, ext, hbx, hby, hbz);
+                    if (touch == 2) umbra = true;
+                    if (touch) {
+                        if (count < cap) { if (count >= 0) out[count] = first + q; count++; }
+                        else truncated = true;
                     }
                 }
-                if (truncated || umbra) break;
             }
-            const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
-            if (i0 && i1) {
-                const bool first0 = a0 <= a1;                              // the child nearest to the surface point first
-                // one stack word: node index | u upper bound quantised UP to qbits bits (conservative)
-                const float bu = fminf(1.0f, fmaxf(0.0f, first0 ? b1 : b0));
-                const int qu = min(qmax, (int)(bu * (float)qmax) + 1);
-                st.put(sp++, (first0 ? n.c1 : n.c0) | (qu << nbits));
-                ni = first0 ? n.c0 : n.c1; nu = first0 ? b0 : b1;
-            } else if (i0) { ni = n.c0; nu = b0; }
-            else if (i1) { ni = n.c1; nu = b1; }
-            else {
-                if (sp == 0) break;
-                const int w = st.get(--sp);
-                ni = w & ((1 << nbits) - 1);
-                nu = (float)((unsigned)w >> nbits) * qinv;
-            }
+            if (truncated || umbra) break;
         }
         if (umbra) {
             // fully shadowed: rayEscapeCount = 0 -> (byte)(0.0 * 255) = 0 -> ModulatePackedColor(color, 0) = opaque black
