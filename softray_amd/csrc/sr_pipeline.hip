@@ -365,8 +365,8 @@ __device__ __forceinline__ int shaft_touches(const TriSlab s, float ex, float ey
     const float Rm = R * 1.001f;
     if (n1 > 2.0f * Rm && n0 < 0.0f) {                          // front-facing for all samples, plane between light and surface point
         const float ulo = -n0 / (n1 + Rm), uhi = -n0 / (n1 - Rm);
-        if (ulo > 2e-3f && uhi < 0.5f) {
-            const float margin = Rm * uhi + 1e-3f * ext;
+        if (ulo > 2e-4f && uhi < 0.5f) {
+            const float margin = Rm * uhi + 3e-5f * ext;             // fp32 evaluation error of an edge function is < 2e-6 * extent
             const float e1 = fminf(p0 + ulo * p1, p0 + uhi * p1), e2 = fminf(q0 + ulo * q1, q0 + uhi * q1), e3 = fminf(r0 + ulo * r1, r0 + uhi * r1);
             if (e1 > margin && e2 > margin && e3 > margin) {
                 // the crossing region must also be inside the root box (hits outside it are no hits: SpatialSubdivision.cs:652)
