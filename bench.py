@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1, help="rayTraceSubPixelRes")
     ap.add_argument("--mode", default="bvh", choices=["bvh", "ref", "brute"])
     ap.add_argument("--depth", type=float, default=1.5)
+    ap.add_argument("--extent", type=float, default=0.05, help="triangle extent of the synthetic soup (SURVEY 8d: 0.05 at 1M, 0.02 at 10M)")
     ap.add_argument("--strip-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="after timing: rank 0 re-renders the whole frame alone and compares it with the gathered one")
@@ -147,7 +148,8 @@ def main():
             dist.init_process_group(args.backend)
 
     # ---- scene resident in HBM (replicated on every rank: 128 MB of records) ----
-    v9, argb, bmin, bmax = sa.unit_cube_scene(args.tris)
+    v9, argb = sa.make_random_triangles(args.tris, 12345, space=1.0 - args.extent, extent=args.extent, origin=-0.5, opaque=True)
+    bmin, bmax = np.array([-0.5] * 3), np.array([0.5] * 3)
     g = sa.GpuScene(local_rank)
     g.set_triangles(v9, argb, bmin, bmax)
     t0 = time.time()

@@ -259,7 +259,14 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     const bool shaft = shadows && f->trace_mode == SR_MODE_BVH && (fc.flags & SR_F_POINT_LIGHT) && fc.shadow_samples <= 128 &&
                        !(f->flags & SR_F_PER_LANE_SHADOWS);
     // samples per band: bounds the hit queue (64 B/sample) and, on the shaft path, the candidate lists (200 B/sample)
-    const long long kMaxBandSamples = shaft ? (8ll << 20) : (32ll << 20);
+    long long kMaxBandSamples = shaft ? (8ll << 20) : (32ll << 20);
+    int round_cap[sr::kShaftRounds];
+    for (int r = 0; r < sr::kShaftRounds; ++r) round_cap[r] = sr::pipeline_round_cap(r);
+    {   // test hooks: shrink the bands / candidate lists so that small frames exercise banding, round 2 and the fallback
+        if (const char* e = std::getenv("SR_BAND_SAMPLES")) kMaxBandSamples = std::max(1ll, std::atoll(e));
+        if (const char* e = std::getenv("SR_ROUND_CAP0")) round_cap[0] = std::min(std::max(1, std::atoi(e)), sr::pipeline_round_cap(0));
+        if (const char* e = std::getenv("SR_ROUND_CAP1")) round_cap[1] = std::min(std::max(1, std::atoi(e)), sr::pipeline_round_cap(1));
+    }
     long long band_rows = std::max<long long>(16, (kMaxBandSamples / ((long long)fc.width * n2)) / 16 * 16);
     band_rows = std::min<long long>(band_rows, ((long long)fc.num_rows + 15) / 16 * 16);
     const long long band_samples = band_rows * fc.width * n2;
@@ -269,7 +276,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         SR_HIP(s->d_fallback.reserve((size_t)band_samples * 4));
         for (int r = 0; r < sr::kShaftRounds; ++r) {
             // round 0 sees every hit; each later round is provisioned for 1/8 of the previous one
-            round_items[r] = r == 0 ? (unsigned)band_samples : (unsigned)std::max<long long>(1024, (long long)round_items[r - 1] / (r == 1 ? 8 : 4));
+            round_items[r] = r == 0 ? (unsigned)band_samples : (unsigned)std::max<long long>(1024, (long long)round_items[r - 1] / 4);
             SR_HIP(s->d_rcount[r].reserve((size_t)round_items[r] * 4));
             SR_HIP(s->d_rcand[r].reserve((size_t)round_items[r] * sr::pipeline_round_cap(r) * 4));
             SR_HIP(s->d_rlist[r].reserve((size_t)round_items[r] * 4));     // round 0: the hits k_shaft left undecided
@@ -296,6 +303,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     P.fallback = shaft ? (unsigned int*)s->d_fallback.p : nullptr;
     for (int r = 0; r < sr::kShaftRounds; ++r) {
         P.round_items[r] = round_items[r];
+        P.round_cap[r] = round_cap[r];
         P.round_list[r] = shaft ? (unsigned int*)s->d_rlist[r].p : nullptr;
         P.round_state[r] = (shaft && r > 0) ? s->d_rstate[r].p : nullptr;
         P.round_cand_count[r] = shaft ? (unsigned int*)s->d_rcount[r].p : nullptr;

@@ -58,6 +58,7 @@ struct PipelineLaunch {
     unsigned int* counters;     // device uint[8]: hits, k_shadow head, items entering round 1.., fallback count, fallback head
     // shaft path (own BVH + point light), kShaftRounds rounds of (k_shaft, k_shadow_test); round 0 covers every hit
     unsigned int  round_items[kShaftRounds];      // capacity (hits) of the round's buffers (round 0: band samples)
+    int           round_cap[kShaftRounds];        // candidate-list length (stride) of the round
     unsigned int* round_list[kShaftRounds];       // device hit indices entering the round (round 0: hits k_shaft left undecided)
     void*         round_state[kShaftRounds];      // device RoundState per item (round 0: nullptr)
     unsigned int* round_cand_count[kShaftRounds]; // device per-item candidate count | truncated flag

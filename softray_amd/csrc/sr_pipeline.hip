@@ -303,7 +303,7 @@ __device__ __forceinline__ bool tri_blocks(const double* p, const SampleRay& r, 
 constexpr int kPacketSlots = 2;          // samples per lane in k_shadow_test: S <= 128
 constexpr int kShaftCap = 48;            // triangles per candidate list in the first round (every hit)
 // later rounds only see the hits whose earlier candidates left samples undecided: longer lists, fewer hits
-constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 160};
+constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 256};
 constexpr int kRecordsPerPass = 16;      // records staged through LDS per pass (2 KB per wave)
 constexpr unsigned kTruncated = 0x80000000u;
 
@@ -807,7 +807,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         const unsigned int* ilist = first ? nullptr : L.round_list[round];
         const long long max_items = first ? max_hits : (long long)std::min<long long>(max_hits, count_cap);
         if (max_items <= 0) break;
-        const int cap = kRoundCap[round];
+        const int cap = L.round_cap[round];
         // ---- k_shaft ----
         pipe_events(L, first ? K_SHAFT : K_SHAFT2, e0, e1);
         if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
@@ -906,7 +906,7 @@ hipError_t launch_pipeline(const PipelineLaunch& L) {
 }
 
 size_t pipeline_hit_record_bytes() { return sizeof(HitRec); }
-int pipeline_round_cap(int round) { return kRoundCap[round]; }
+int pipeline_round_cap(int round) { return kRoundCap[round]; }   // default list length of a round
 size_t pipeline_round_state_bytes() { return sizeof(RoundState); }
 
 }  // namespace sr

@@ -199,3 +199,50 @@ def test_error_codes_on_gpu(obj_pair):
     with pytest.raises(sa.SoftrayError) as e:
         g2.render(as_sr(make_frame(16)))
     assert e.value.code == sa._lib.SR_ERR_NO_MODEL   # Render() without a model draws nothing (Renderer.cs:736-739)
+
+
+def test_shadow_sample_variants(obj_pair):
+    """ShadowMethod with other sample tables: 1 sample / zero offset (hard-shadow variant), odd counts, a caller-supplied
+    offset table (what the C# shim passes), and > 128 samples (per-lane kernel instead of the shaft path)."""
+    g, o = obj_pair
+    rnd = orc.Random(4242)
+    for count in (1, 7, 64, 100, 130):
+        f = make_frame(72, 56, shadows=True, shadow_samples=count)
+        if count == 1:
+            table = np.zeros((1, 3))
+        elif count == 100:
+            table = orc.area_light_offsets(1234567890, 100) * 1.5         # a different light radius
+        else:
+            table = None
+        if table is not None:
+            table = np.ascontiguousarray(table)
+            f.area_light_offsets = table.ctypes.data
+        want, _ = o.render(f, threads=NCPU)
+        for mode in (sa.MODE_BVH, sa.MODE_REF_TREE):
+            got, _ = render_both(g, f, mode)
+            assert np.array_equal(got, want), (count, mode)
+
+
+def test_pipeline_bands_rounds_and_fallback(monkeypatch):
+    """Force tiny row bands and tiny candidate lists so that a small frame goes through several bands, the second shaft
+    round and the exact wave-per-hit fallback; the image must not change."""
+    v9, argb, bmin, bmax = unit_cube_scene(20000)
+    g = sa.GpuScene(0); o = orc.Scene()
+    for s in (g, o):
+        s.set_triangles(v9, argb, bmin, bmax)
+    g.build((sa.MODE_BVH,)); assert o.build_tree() == 0
+    f = make_frame(96, 80, depth=1.5, shadows=True)
+    want, _ = o.render(f, threads=NCPU)
+    base, _ = g.render(as_sr(f, sa.MODE_BVH))
+    assert np.array_equal(base, want)
+    monkeypatch.setenv("SR_BAND_SAMPLES", "2000")
+    monkeypatch.setenv("SR_ROUND_CAP0", "2")
+    monkeypatch.setenv("SR_ROUND_CAP1", "3")
+    got, _ = g.render(as_sr(f, sa.MODE_BVH))
+    assert np.array_equal(got, want)
+    c = g.debug_counters()
+    assert c[2] > 0 and c[3] > 0, c            # round 2 and the fallback were really exercised
+    f2 = make_frame(96, 80, depth=1.5, shadows=True, sub_pixel_res=2, focal_blur=True)
+    want2, _ = o.render(f2, threads=NCPU)
+    got2, _ = g.render(as_sr(f2, sa.MODE_BVH))
+    assert np.array_equal(got2, want2)
