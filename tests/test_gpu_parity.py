@@ -246,3 +246,41 @@ def test_pipeline_bands_rounds_and_fallback(monkeypatch):
     want2, _ = o.render(f2, threads=NCPU)
     got2, _ = g.render(as_sr(f2, sa.MODE_BVH))
     assert np.array_equal(got2, want2)
+
+
+def test_full_size_properties():
+    """BASELINE-size checks (1 M triangles, up to 4096^2) through size-independent properties: the three shadow schedules
+    agree, the union of interleaved strips is the frame, rendering is idempotent, the own BVH and the literal reference
+    tree give the same image on the device, and a band of rows equals the CPU oracle bit for bit."""
+    v9, argb, bmin, bmax = sa.unit_cube_scene(1000000)
+    g = sa.GpuScene(0)
+    g.set_triangles(v9, argb, bmin, bmax)
+    g.build((sa.MODE_BVH, sa.MODE_REF_TREE))
+    # (a) 4096^2, shading + 100-sample shadows
+    f = make_frame(4096, depth=1.5, shadows=True, mode=orc.MODE_REF_TREE)
+    a, stats = g.render(as_sr(f, sa.MODE_BVH))
+    assert stats[0] == 4096 * 4096
+    again, _ = g.render(as_sr(f, sa.MODE_BVH))
+    assert np.array_equal(a, again)
+    lanes, _ = g.render(as_sr(f, sa.MODE_BVH, per_lane=True))
+    assert np.array_equal(a, lanes)
+    a2 = a.reshape(4096, 4096)
+    for k in range(4):
+        fs = make_frame(4096, depth=1.5, shadows=True, strips=(16, 4, k))
+        px, _ = g.render(as_sr(fs, sa.MODE_BVH))
+        rows = [r for r in range(4096) if (r // 16) % 4 == k]
+        assert np.array_equal(px.reshape(len(rows), 4096), a2[rows]), k
+    assert len(np.unique(a)) > 10000
+    # (b) own BVH == literal reference tree on the device (primary + shading 1024^2; shadows 384^2)
+    for res, kw in ((1024, dict()), (384, dict(shadows=True))):
+        fb = make_frame(res, depth=1.5, **kw)
+        x, _ = g.render(as_sr(fb, sa.MODE_BVH))
+        y, _ = g.render(as_sr(fb, sa.MODE_REF_TREE))
+        assert np.array_equal(x, y), res
+    # (c) two rows of the 4096^2 frame against the CPU oracle (reference tree 15/25)
+    o = orc.Scene()
+    o.set_triangles(v9, argb, bmin, bmax)
+    assert o.build_tree() == 0
+    fo = make_frame(4096, depth=1.5, shadows=True, start_row=2047, end_row=2048)
+    want, _ = o.render(fo, threads=NCPU)
+    assert np.array_equal(want.reshape(4096, 4096)[2047:2049], a2[2047:2049])
