@@ -68,6 +68,8 @@ def make_frame(args, strips=None):
         f.light_dir_view[i] = v
     for i, v in enumerate(lp):
         f.light_pos_view[i] = v
+    if args.bounces > 0:
+        f.max_bounces, f.reflectivity = args.bounces, args.reflectivity
     if args.shadows == 1:                                            # hard-shadow variant: one sample, zero offset
         make_frame.zero = np.zeros(3)
         f.area_light_offsets = make_frame.zero.ctypes.data
@@ -123,6 +125,8 @@ def main():
     ap.add_argument("--spp", type=int, default=1, help="rayTraceSubPixelRes")
     ap.add_argument("--mode", default="bvh", choices=["bvh", "ref", "brute"])
     ap.add_argument("--depth", type=float, default=1.5)
+    ap.add_argument("--bounces", type=int, default=0, help="config-5 extension: mirror bounces (unpinned; one-kernel renderer)")
+    ap.add_argument("--reflectivity", type=float, default=0.5)
     ap.add_argument("--extent", type=float, default=0.05, help="triangle extent of the synthetic soup (SURVEY 8d: 0.05 at 1M, 0.02 at 10M)")
     ap.add_argument("--strip-rows", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -271,6 +275,22 @@ def main():
         got = (sg.full if sg else local).cpu().numpy().reshape(-1)
         out["verify"] = {"full_frame_equal": bool(np.array_equal(got, ref)), "crc": int(np.bitwise_xor.reduce(ref.view(np.uint32)))}
         assert out["verify"]["full_frame_equal"], "gathered frame differs from the single-process frame"
+    # ---- the same frame without ShadowMethod (rayTraceShadows = false): the "primary rays only" rate, same scene/pose ----
+    if world == 1 and args.shadows > 0:
+        import copy
+        a0 = copy.copy(args)
+        a0.shadows = 0
+        f0 = make_frame(a0)
+        for _ in range(max(1, args.warmup)):
+            g.render_device(f0, local.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            g.render_device(f0, local.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        dt0 = (time.perf_counter() - t1) / args.steps
+        out["primary_only"] = {"value": primary_rays / dt0 / 1e6, "unit": "Mrays/s", "ms_per_step": dt0 * 1e3,
+                               "note": "same scene, pose and resolution with rayTraceShadows = false (shading on): primary rays only"}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -105,7 +105,10 @@ typedef struct {
                                         [start_row,end_row] with (r / strip_rows) % strip_count ==
                                         strip_index into a COMPACT buffer (owned rows in order).
                                         strip_count == 0: off, pixels is the full W*H surface            */
-    int32_t  max_bounces;            /* reserved (config-5 mirror-reflection extension); must be 0       */
+    int32_t  max_bounces;            /* 0 = the reference.  1..16: EXTENSION for config 5 (no reference counterpart,
+                                        parity unpinned): mirror bounces r = dir - n*(2 dir.n) from pos + n*0.001,
+                                        each level coloured by the same shading/shadow chain, colours blended per
+                                        channel ((s*(255-k))>>8) + ((r*k)>>8), k = (byte)(reflectivity*255)       */
     double   transform[12];          /* rows 0..2 of Instance._transform        (Instance.cs:134)        */
     double   inv_transform[12];      /* rows 0..2 of Instance._inverseTransform (Instance.cs:135)        */
     double   position_z;             /* Instance.Position.z (:1717, Instance.cs:182)                     */
@@ -115,7 +118,7 @@ typedef struct {
     double   ambient, shininess;     /* ambientLight_intensity, specularLight_shininess (:38,:41)        */
     double   light_dir_view[3];      /* directionalLight_dir (:39)                                       */
     double   light_pos_view[3];      /* positionalLight_pos (:40)                                        */
-    double   reflectivity;           /* reserved; must be 0                                              */
+    double   reflectivity;           /* 0..1, only read when max_bounces > 0                              */
     const double* area_light_offsets;/* optional [shadow_samples][3] (e.g. produced by the C# shim with the
                                         real System.Random); NULL => derived from random_seed             */
 } sr_frame;

@@ -741,12 +741,16 @@ double TraceRaysForSoftShadows(const FrameCtx& fc, Vec surfacePos, Vec surfaceNo
 
 /* The decorator chain for one camera ray, flags as set per frame (Renderer.cs:1590-1649):
  * LightFieldColor(off) > AmbientOcclusion(off) > Shadow > PathTracing(off) > Shading > LightFieldTri(off) > root
- * then TraceRayComplex (Renderer.cs:1850-1885): miss -> BackgroundColorWithAlpha. */
-uint32_t TraceRayComplex(const FrameCtx& fc, Vec start, Vec dir, Counters& primary, Counters& secondary) {
-    Hit info;
-    if (!RootIntersect(*fc.scene, fc.mode, start, dir, info, primary)) {
-        return fc.f->background_argb | 0xFF000000u;             /* Renderer.cs:325-331,1860 */
-    }
+ * then TraceRayComplex (Renderer.cs:1850-1885): miss -> BackgroundColorWithAlpha.
+ *
+ * max_bounces > 0 is the config-5 EXTENSION (no counterpart in the reference; "parity unpinned", the definition is
+ * this code): a Whitted mirror bounce.  After the chain has coloured a hit, the ray is reflected about the surface
+ * normal, r = dir - n * (2.0 * dir.n), restarted at pos + n * 0.001 (the raySurfaceOffset of PathTracingMethod.cs:10),
+ * traced through the same chain, and the two packed colours are blended per channel with integer arithmetic:
+ * c = ((surface * (255 - k)) >> 8) + ((reflected * k) >> 8), k = (byte)(reflectivity * 255), alpha 0xFF.  A reflected
+ * ray that misses sees the background colour.  Depth is limited to max_bounces reflections. */
+uint32_t ChainColor(const FrameCtx& fc, const Hit& info0, Counters& secondary) {
+    Hit info = info0;
     if (fc.f->flags & ORC_F_SHADING) {                          /* ShadingMethod.IntersectRay :36-68 */
         Vec pos_View = fc.xf.TransformPosToView(info.pos);
         Vec normal_View = fc.xf.TransformDirection(info.normal);
@@ -759,6 +763,46 @@ uint32_t TraceRayComplex(const FrameCtx& fc, Vec start, Vec dir, Counters& prima
         info.color = ModulatePackedColor(info.color, lightIntensityByte);
     }
     return info.color;
+}
+
+uint32_t TraceRayComplex(const FrameCtx& fc, Vec start, Vec dir, Counters& primary, Counters& secondary) {
+    const uint32_t background = fc.f->background_argb | 0xFF000000u;   /* Renderer.cs:325-331,1860 */
+    Hit info;
+    if (!RootIntersect(*fc.scene, fc.mode, start, dir, info, primary)) return background;
+    const int maxBounces = fc.f->max_bounces;
+    if (maxBounces <= 0) return ChainColor(fc, info, secondary);
+
+    /* ---- extension: mirror bounces ---- */
+    uint32_t surface[17];
+    int levels = 0;
+    uint32_t tail = background;                                  /* what the deepest ray saw */
+    bool tailIsSurface = false;
+    for (;;) {
+        surface[levels++] = ChainColor(fc, info, secondary);
+        if (levels > maxBounces) { tailIsSurface = true; break; }
+        Vec n = info.normal;
+        Vec r = dir - n * (2.0 * Dot(dir, n));
+        Vec rstart = info.pos + n * 0.001;
+        Hit next;
+        if (!RootIntersect(*fc.scene, fc.mode, rstart, r, next, secondary)) break;
+        start = rstart; dir = r; info = next;
+    }
+    uint32_t k = ToByte(fc.f->reflectivity * 255.0);
+    uint32_t color;
+    int i;
+    if (tailIsSurface) { color = surface[levels - 1]; i = levels - 2; }
+    else { color = tail; i = levels - 1; }
+    for (; i >= 0; --i) {
+        uint32_t sfc = surface[i];
+        uint32_t out = 255u << 24;
+        for (int sh = 16; sh >= 0; sh -= 8) {
+            uint32_t a = (sfc >> sh) & 0xffu, b = (color >> sh) & 0xffu;
+            uint32_t c = ((a * (255u - k)) >> 8) + ((b * k) >> 8);
+            out |= (c & 0xffu) << sh;
+        }
+        color = out;
+    }
+    return color;
 }
 
 /* Renderer.RaytraceBlock, one pixel (Renderer.cs:1718-1828) */
@@ -939,6 +983,7 @@ int orc_render(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t
     if (!s->haveBox || s->tris.empty()) return -3;               /* no model pinned: Renderer.cs:736-739 */
     if (f->trace_mode == ORC_MODE_REF_TREE && !s->haveTree) return -4;
     if (f->sub_pixel_res < 1) return -5;
+    if (f->max_bounces < 0 || f->max_bounces > 16 || !(f->reflectivity >= 0.0 && f->reflectivity <= 1.0)) return -6;
     FrameCtx fc;
     fc.scene = s;
     fc.f = f;

@@ -150,7 +150,8 @@ int validate_frame(const sr_frame* f) {
     if (f->strip_count < 0 || (f->strip_count > 0 && (f->strip_rows <= 0 || f->strip_index < 0 || f->strip_index >= f->strip_count)))
         return fail(SR_ERR_INVALID_ARG, "bad strip parameters");
     if (f->shadow_samples < 0 || f->shadow_samples > 4096) return fail(SR_ERR_INVALID_ARG, "shadow_samples out of range");
-    if (f->max_bounces != 0 || f->reflectivity != 0.0) return fail(SR_ERR_UNSUPPORTED, "reflection extension is not implemented");
+    if (f->max_bounces < 0 || f->max_bounces > 16 || !(f->reflectivity >= 0.0 && f->reflectivity <= 1.0))
+        return fail(SR_ERR_INVALID_ARG, "max_bounces must be 0..16 and reflectivity 0..1");
     return SR_OK;
 }
 
@@ -191,6 +192,8 @@ int prepare_frame(sr_scene* s, const sr_frame* f, sr::FrameConst& fc) {
         fc.start_world[r] = vx * it[4 * r] + vy * it[4 * r + 1] + vz * it[4 * r + 2];
     }
     fc.aspect = (double)f->height / (double)f->width;               // Renderer.cs:621
+    fc.max_bounces = f->max_bounces;
+    fc.reflectivity = f->reflectivity;
 
     // area-light offsets (ShadowMethod.cs:63-73)
     s->offsets_host.resize((size_t)fc.shadow_samples * 3);
@@ -236,7 +239,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     if (!s->rowmap_host.empty())
         SR_HIP(hipMemcpyAsync(s->d_rowmap.p, s->rowmap_host.data(), s->rowmap_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     if (fc.num_rows == 0) return SR_OK;
-    if (f->flags & SR_F_SINGLE_KERNEL) {
+    if ((f->flags & SR_F_SINGLE_KERNEL) || f->max_bounces > 0) {      // mirror bounces: the one-kernel renderer traces them inline
         sr::RenderLaunch L{};
         L.sc = dev_scene(s);
         L.fc = fc;

@@ -459,15 +459,67 @@ __device__ uint32_t soft_shadow(const DevScene& sc, const FrameConst& fc, const 
     return to_byte(frac * 255);
 }
 
-// TraceRayComplex with the decorator chain of one frame
+// per-channel blend of two packed colours: ((s * (255 - k)) >> 8) + ((r * k) >> 8), alpha 0xFF.
+// Deliberately __noinline__ and composed with '+': inlined into the fold loop (ROCm 7.2 hipcc -O3, gfx950) the
+// middle (green) byte came out one too small -- a byte-select peephole miscompile that the GPU-vs-oracle test caught.
+__device__ __noinline__ uint32_t blend_packed(uint32_t sfc, uint32_t refl, uint32_t k) {
+    uint32_t out = 255u << 24;
+    const uint32_t ik = 255u - k;
+    uint32_t sr = (sfc >> 16) & 0xffu, sg = (sfc >> 8) & 0xffu, sb = sfc & 0xffu;
+    uint32_t rr = (refl >> 16) & 0xffu, rg = (refl >> 8) & 0xffu, rb = refl & 0xffu;
+    uint32_t cr = ((sr * ik) >> 8) + ((rr * k) >> 8);
+    uint32_t cg = ((sg * ik) >> 8) + ((rg * k) >> 8);
+    uint32_t cb = ((sb * ik) >> 8) + ((rb * k) >> 8);
+    out += (cr & 0xffu) << 16;
+    out += (cg & 0xffu) << 8;
+    out += (cb & 0xffu);
+    return out;
+}
+
+// TraceRayComplex with the decorator chain of one frame.
+// fc.max_bounces > 0: the config-5 extension (no counterpart in the reference, definition shared with the CPU checker):
+// mirror bounce r = dir - n * (2.0 * dir.n) from pos + n * 0.001, each level coloured by the same chain, packed colours
+// blended per channel c = ((surface * (255 - k)) >> 8) + ((reflected * k) >> 8), k = (byte)(reflectivity * 255).
 template <int MODE, bool EXTRA>
 __device__ uint32_t trace_camera_ray(const DevScene& sc, const FrameConst& fc, const Rec128* tris, const Rec128* extra,
                                      const double* offsets, Stack st, D3 s, D3 d, Ctr& prim, Ctr& sec) {
     Hit h;
     if (!root_intersect<MODE, false, EXTRA>(sc, tris, extra, st, s, d, h, prim)) return fc.background;
-    uint32_t color = h.color;
-    if (fc.flags & 1u) color = shade(fc, h.pos, h.nrm, color);
-    if (fc.flags & 2u) color = modulate(color, soft_shadow<MODE, EXTRA>(sc, fc, tris, extra, offsets, st, h.pos, h.nrm, sec));
+    const int maxb = fc.max_bounces;
+    constexpr int kMaxLevels = 17;                                 // max_bounces <= 16
+    uint32_t surface[kMaxLevels];                                  // only ever indexed with unrolled constants: stays in registers
+#pragma unroll
+    for (int i = 0; i < kMaxLevels; ++i) surface[i] = 0u;
+    int levels = 0;
+    bool tail_is_surface = false;
+    for (;;) {
+        uint32_t color = h.color;
+        if (fc.flags & 1u) color = shade(fc, h.pos, h.nrm, color);
+        if (fc.flags & 2u) color = modulate(color, soft_shadow<MODE, EXTRA>(sc, fc, tris, extra, offsets, st, h.pos, h.nrm, sec));
+        if (maxb <= 0) return color;                               // the reference's behaviour
+#pragma unroll
+        for (int i = 0; i < kMaxLevels; ++i) if (i == levels) surface[i] = color;
+        ++levels;
+        if (levels > maxb) { tail_is_surface = true; break; }
+        const D3 n = h.nrm;
+        const D3 r = d - n * (2.0 * dot(d, n));
+        const D3 rs = h.pos + n * 0.001;
+        Hit nx;
+        if (!root_intersect<MODE, false, EXTRA>(sc, tris, extra, st, rs, r, nx, sec)) break;
+        d = r;
+        h = nx;
+    }
+    const uint32_t k = to_byte(fc.reflectivity * 255.0);
+    // fold from the deepest level back to the camera ray
+    uint32_t color = fc.background;
+    const int last = tail_is_surface ? levels - 2 : levels - 1;    // deepest level that gets blended with what lies beyond it
+#pragma unroll
+    for (int i = kMaxLevels - 1; i >= 0; --i) {
+        if (tail_is_surface && i == levels - 1) color = surface[i];
+        if (i <= last) {
+            color = blend_packed(surface[i], color, k);
+        }
+    }
     return color;
 }
 

@@ -93,7 +93,9 @@ struct FrameConst {
     double   light_dir_model[3], light_pos_model[3];
     double   start_world[3];     // R^-1 * (0,0,-Position.z), Renderer.cs:1717
     double   aspect;             // (double)height / (double)width, Renderer.cs:621
-    int32_t  debug, debug_pad;   // SR_DEBUG experiment switch (0 in production)
+    int32_t  debug;              // SR_DEBUG experiment switch (0 in production)
+    int32_t  max_bounces;        // config-5 extension: mirror bounces (0 = the reference's behaviour)
+    double   reflectivity;
     double   light_radius;       // max |area-light offset| (0.2 for the reference table): bounds the shadow shaft
 };
 

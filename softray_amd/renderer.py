@@ -208,6 +208,8 @@ class Renderer:
         self.gpuTraceMode = None              # None: REF_TREE if rayTraceSubdivision else BRUTE; or MODE_BVH
         self.gpuTreeMaxDepth = 0              # 0 => SpatialSubdivision defaults 15 / 25
         self.gpuTreeMaxGeometryPerNode = 0
+        self.gpuMaxBounces = 0                # config-5 extension: mirror bounces (0 = reference behaviour)
+        self.gpuReflectivity = 0.0
         self.Instances = []
         self.ExtraGeometryToRaytrace = GeometryCollection()
         self.CachePath = "./cache"
@@ -367,6 +369,8 @@ class Renderer:
             f.light_dir_view[i] = v
         for i, v in enumerate(self.positionalLight_pos):
             f.light_pos_view[i] = v
+        f.max_bounces = self.gpuMaxBounces
+        f.reflectivity = self.gpuReflectivity
         f.area_light_offsets = None
         return f
 

@@ -191,10 +191,10 @@ def test_rows_and_strips_on_gpu(obj_pair):
 def test_error_codes_on_gpu(obj_pair):
     g, _ = obj_pair
     f = as_sr(make_frame(16))
-    f.max_bounces = 2
+    f.max_bounces = 20
     with pytest.raises(sa.SoftrayError) as e:
         g.render(f)
-    assert e.value.code == sa._lib.SR_ERR_UNSUPPORTED
+    assert e.value.code == sa._lib.SR_ERR_INVALID_ARG
     g2 = sa.GpuScene(0)
     with pytest.raises(sa.SoftrayError) as e:
         g2.render(as_sr(make_frame(16)))
@@ -284,3 +284,34 @@ def test_full_size_properties():
     fo = make_frame(4096, depth=1.5, shadows=True, start_row=2047, end_row=2048)
     want, _ = o.render(fo, threads=NCPU)
     assert np.array_equal(want.reshape(4096, 4096)[2047:2049], a2[2047:2049])
+
+
+def test_reflection_extension_matches_oracle():
+    """Config-5 extension (mirror bounces; no reference counterpart, the oracle is the definition): device == oracle."""
+    v9, argb, bmin, bmax = load_obj3ds()
+    prims = c1_spheres()
+    prims.append((1, 0xff808080, [0, -0.45, 0, 0, 1, 0]))
+    g = sa.GpuScene(0); o = orc.Scene()
+    for s_ in (g, o):
+        s_.set_triangles(v9, argb, bmin, bmax)
+        s_.set_extra(prims)
+    g.build((sa.MODE_REF_TREE, sa.MODE_BVH)); assert o.build_tree() == 0
+    base, _ = o.render(make_frame(80, depth=3.0), threads=NCPU)
+    for bounces, refl, kw in ((1, 0.5, dict()), (4, 0.3, dict(shadows=True)), (4, 1.0, dict(sub_pixel_res=2)), (2, 0.0, dict())):
+        f = make_frame(80, depth=3.0, **kw)
+        f.max_bounces, f.reflectivity = bounces, refl
+        want, _ = o.render(f, threads=NCPU)
+        for mode in (sa.MODE_REF_TREE, sa.MODE_BRUTE, sa.MODE_BVH):
+            got, _ = g.render(as_sr(f, mode))
+            assert np.array_equal(got, want), (bounces, refl, mode)
+        if refl > 0 and not kw:
+            assert not np.array_equal(want, base)
+    v9, argb, bmin, bmax = unit_cube_scene(30000)
+    g.set_triangles(v9, argb, bmin, bmax); o.set_triangles(v9, argb, bmin, bmax)
+    g.set_extra([]); o.set_extra([])
+    g.build((sa.MODE_BVH,)); assert o.build_tree() == 0
+    f = make_frame(96, depth=1.5)
+    f.max_bounces, f.reflectivity = 4, 0.4
+    want, _ = o.render(f, threads=NCPU)
+    got, _ = g.render(as_sr(f, sa.MODE_BVH))
+    assert np.array_equal(got, want)
