@@ -169,6 +169,8 @@ public:
     int rayTraceStartRow = 0, rayTraceEndRow = 0;
     // MI355X additions: which structure the device walks (-1: REF_TREE if rayTraceSubdivision else BRUTE)
     int gpuTraceMode = -1;
+    int gpuMaxBounces = 0;          // config-5 extension: mirror bounces (0 = the reference's behaviour)
+    double gpuReflectivity = 0.0;
     std::vector<std::shared_ptr<Instance>> Instances;
     Raytrace::GeometryCollection ExtraGeometryToRaytrace;
 
@@ -245,6 +247,8 @@ public:
                   (pointLighting ? SR_F_POINT_LIGHT : 0u) | (specularLighting ? SR_F_SPECULAR : 0u);
         f.random_seed = rayTraceRandomSeed;
         f.trace_mode = Mode();
+        f.max_bounces = gpuMaxBounces;
+        f.reflectivity = gpuReflectivity;
         double pos[3] = {instance.Position.x, instance.Position.y, instance.Position.z};
         sr_instance_matrices(pos, instance.Yaw, instance.Pitch, instance.Roll, f.transform, f.inv_transform);   // Instance.cs:134-135
         f.position_z = instance.Position.z;
