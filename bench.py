@@ -129,6 +129,7 @@ def main():
     ap.add_argument("--reflectivity", type=float, default=0.5)
     ap.add_argument("--extent", type=float, default=0.05, help="triangle extent of the synthetic soup (SURVEY 8d: 0.05 at 1M, 0.02 at 10M)")
     ap.add_argument("--strip-rows", type=int, default=16)
+    ap.add_argument("--device-build", action="store_true", help="build the BVH on the GPU (LBVH) instead of the host SAH builder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verify", action="store_true", help="after timing: rank 0 re-renders the whole frame alone and compares it with the gathered one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
@@ -157,7 +158,8 @@ def main():
     g = sa.GpuScene(local_rank)
     g.set_triangles(v9, argb, bmin, bmax)
     t0 = time.time()
-    g.build(({"bvh": sa.MODE_BVH, "ref": sa.MODE_REF_TREE}.get(args.mode),) if args.mode != "brute" else ())
+    g.build(({"bvh": sa.MODE_BVH, "ref": sa.MODE_REF_TREE}.get(args.mode),) if args.mode != "brute" else (),
+            on_device=args.device_build and args.mode == "bvh")
     build_s = time.time() - t0
 
     strips = (args.strip_rows, world, rank) if world > 1 else None

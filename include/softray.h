@@ -143,6 +143,10 @@ int  sr_set_extra_geometry(sr_scene*, const sr_prim* prims, int32_t n);
  * <=0 => the defaults 15 / 25, :269-270; SR_ERR_OUT_OF_RANGE if a vertex is outside the box);
  * BVH: the library's own BVH; BRUTE needs nothing.  Host work + H2D copies. */
 int  sr_build(sr_scene*, uint32_t modes, int32_t max_depth, int32_t max_per_leaf);
+/* OR-ed into `modes`: build the own BVH on the GPU (Morton-ordered LBVH, sr_lbvh.hip; SURVEY 8f "next" row 2) instead of
+ * the host's binned-SAH builder.  Pixels are identical (the traversal is exact for any conservative BVH); the tree is
+ * built in milliseconds instead of seconds, at the price of a somewhat slower traversal. */
+#define SR_BUILD_ON_DEVICE 0x100u
 /* out = TreeDepth, NumNodes, NumLeafNodes, NumInternalNodes (SpatialSubdivision.cs:317-335) */
 int  sr_tree_stats(const sr_scene*, int32_t out[4]);
 

@@ -19,6 +19,7 @@ F_SINGLE_KERNEL = 1 << 8
 F_PER_LANE_SHADOWS = 1 << 9
 MODE_REF_TREE, MODE_BRUTE, MODE_BVH = 0, 1, 2
 TARGET_ROOT = 0x100
+BUILD_ON_DEVICE = 0x100
 
 # every symbol include/softray.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [

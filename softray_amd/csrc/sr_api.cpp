@@ -69,6 +69,8 @@ struct sr_scene {
     sr::RootBox root{};
     sr::RefTree ref;
     sr::Bvh     bvh;
+    bool        bvh_on_device = false;   // built by sr_lbvh.hip: no host copy of the nodes
+    size_t      bvh_num_nodes = 0;
     // device state
     DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab;
     DBuf d_offsets, d_rowmap, d_pixels, d_stats, d_io[9], d_hits, d_samples, d_counters, d_fallback, d_rlist[sr::kShaftRounds], d_rstate[sr::kShaftRounds], d_rcount[sr::kShaftRounds], d_rcand[sr::kShaftRounds];
@@ -99,7 +101,7 @@ int sync_geometry(sr_scene* s, uint32_t need_mode) {
         SR_HIP(s->d_rleaf.upload(s->ref.leaf_tris));
         s->ref_dirty = false;
     }
-    if (need_mode == SR_MODE_BVH && s->bvh_dirty) {
+    if (need_mode == SR_MODE_BVH && s->bvh_dirty && !s->bvh_on_device) {
         SR_HIP(s->d_bnodes.upload(s->bvh.nodes));
         std::vector<sr::Rec128> ordered(s->bvh.order.size());
         for (size_t i = 0; i < ordered.size(); ++i) ordered[i] = s->tri_recs[s->bvh.order[i]];
@@ -110,6 +112,7 @@ int sync_geometry(sr_scene* s, uint32_t need_mode) {
             slabs[i] = sr::make_tri_slab({p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}, s->root.centre);
         }
         SR_HIP(s->d_bslab.upload(slabs));
+        s->bvh_num_nodes = s->bvh.nodes.size();
         s->bvh_dirty = false;
     }
     return SR_OK;
@@ -124,7 +127,7 @@ sr::DevScene dev_scene(const sr_scene* s) {
     d.bnodes = (const sr::BvhNode*)s->d_bnodes.p; d.btris = (const sr::Rec128*)s->d_btris.p; d.bdepth = s->bvh.depth;
     d.bslab = (const sr::TriSlab*)s->d_bslab.p;
     d.bnode_bits = 1;
-    while ((1ull << d.bnode_bits) < s->bvh.nodes.size() + 1 && d.bnode_bits < 26) d.bnode_bits++;
+    while ((1ull << d.bnode_bits) < s->bvh_num_nodes + 1 && d.bnode_bits < 26) d.bnode_bits++;
     d.root = s->root;
     return d;
 }
@@ -381,6 +384,7 @@ int sr_set_triangles(sr_scene* s, const double* v9, const uint32_t* argb, int64_
     s->have_model = true;
     s->ref = sr::RefTree();
     s->bvh = sr::Bvh();
+    s->bvh_on_device = false;
     s->tris_dirty = s->ref_dirty = s->bvh_dirty = true;
     return SR_OK;
 }
@@ -418,16 +422,51 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
             return fail(SR_ERR_OUT_OF_RANGE, "A triangle vertex is outside the bounding box");
         s->ref_dirty = true;
     }
-    if (modes & (1u << SR_MODE_BVH)) {
+    const bool on_device = (modes & SR_BUILD_ON_DEVICE) != 0 && s->argb.size() > 64;
+    if ((modes & (1u << SR_MODE_BVH)) && on_device) {
+        // ---- LBVH built by the GPU (sr_lbvh.hip) ----
+        if (s->device < 0) return fail(SR_ERR_NO_DEVICE, "SR_BUILD_ON_DEVICE needs a HIP device");
+        int rc = use_device(s);
+        if (rc) return rc;
+        if ((rc = sync_geometry(s, SR_MODE_BRUTE))) return rc;            // d_tris
+        const size_t n = s->argb.size();
+        DBuf d_v9, d_slab;
+        SR_HIP(d_v9.upload(s->v9));
+        {
+            std::vector<sr::TriSlab> slabs(n);
+            for (size_t i = 0; i < n; ++i) {
+                const double* p = &s->v9[i * 9];
+                slabs[i] = sr::make_tri_slab({p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}, s->root.centre);
+            }
+            SR_HIP(d_slab.upload(slabs));
+        }
+        SR_HIP(s->d_bnodes.reserve(n * sizeof(sr::BvhNode)));
+        SR_HIP(s->d_btris.reserve(n * sizeof(sr::Rec128)));
+        SR_HIP(s->d_bslab.reserve(n * sizeof(sr::TriSlab)));
+        int nn = 0, depth = 0;
+        hipError_t e = sr::build_bvh_device((const double*)d_v9.p, (int)n, s->root, (const sr::Rec128*)s->d_tris.p, (const sr::TriSlab*)d_slab.p,
+                                            (sr::BvhNode*)s->d_bnodes.p, (sr::Rec128*)s->d_btris.p, (sr::TriSlab*)s->d_bslab.p, &nn, &depth, nullptr);
+        d_v9.release();
+        d_slab.release();
+        if (e != hipSuccess) return hip_fail(e, "build_bvh_device");
+        if (depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
+        s->bvh = sr::Bvh();
+        s->bvh.built = true;
+        s->bvh.depth = depth;
+        s->bvh_num_nodes = (size_t)nn;
+        s->bvh_on_device = true;
+        s->bvh_dirty = false;
+    } else if (modes & (1u << SR_MODE_BVH)) {
         sr::build_bvh(s->v9, s->root, s->bvh);
         if (s->bvh.depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
+        s->bvh_on_device = false;
         s->bvh_dirty = true;
     }
     if (s->device >= 0) {
         int rc = use_device(s);
         if (rc) return rc;
         if (modes & (1u << SR_MODE_REF_TREE)) if ((rc = sync_geometry(s, SR_MODE_REF_TREE))) return rc;
-        if (modes & (1u << SR_MODE_BVH)) if ((rc = sync_geometry(s, SR_MODE_BVH))) return rc;
+        if ((modes & (1u << SR_MODE_BVH)) && !s->bvh_on_device) if ((rc = sync_geometry(s, SR_MODE_BVH))) return rc;
         if ((rc = sync_geometry(s, SR_MODE_BRUTE))) return rc;
     }
     return SR_OK;

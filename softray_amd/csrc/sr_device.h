@@ -77,6 +77,10 @@ size_t pipeline_hit_record_bytes();
 int pipeline_round_cap(int round);
 size_t pipeline_round_state_bytes();
 
+// Own BVH built on the device (sr_lbvh.hip).  Inputs in TriangleIndex order, outputs caller-allocated (n entries each).
+hipError_t build_bvh_device(const double* d_v9, int n, const RootBox& root, const Rec128* d_tris, const TriSlab* d_slab_in,
+                            BvhNode* d_nodes, Rec128* d_btris, TriSlab* d_bslab, int* num_nodes, int* depth, hipStream_t stream);
+
 struct TraceLaunch {
     DevScene sc;
     int32_t  mode;              // SR_MODE_*

@@ -1,0 +1,235 @@
+// sr_lbvh.hip -- the own BVH built ON THE DEVICE (SURVEY.md 8f "next" row 2: at 1M-10M triangles the host build
+// dominates end-to-end time).  Morton-ordered LBVH (Karras 2012): 63-bit Morton codes of the triangle-box centres ->
+// radix sort (rocPRIM through hipCUB) -> binary radix tree -> bottom-up fp32 boxes -> subtrees of <= 4 triangles are
+// collapsed into leaves -> the same 64-byte BvhNode / leaf-ordered record layout the SAH builder produces.
+//
+// Any BVH with conservative boxes gives the same pixels: the traversal (sr_trace.h) decides hits with the reference's
+// FP64 triangle arithmetic and picks the nearest (ties -> lowest TriangleIndex) whatever the tree shape.  Boxes are
+// rounded outward (directed double->float conversion) and padded by 2^-16 * extent exactly like sr_host.cpp::store().
+#include "sr_device.h"
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <vector>
+
+namespace sr {
+
+namespace {
+
+constexpr int kLeafMax = 4;
+
+struct FBox { float lo[3], hi[3]; };
+
+__device__ __forceinline__ unsigned long long spread21(unsigned long long x) {   // 21 bits -> every third bit
+    x &= 0x1fffffull;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+
+// per triangle: conservative fp32 box (relative to the root centre, padded) + Morton key of its centre
+__global__ void k_lbvh_keys(const double* __restrict__ v9, int n, RootBox root, float pad, FBox* __restrict__ tbox,
+                            unsigned long long* __restrict__ keys, unsigned int* __restrict__ vals) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = v9 + (size_t)i * 9;
+    double lo[3], hi[3];
+    for (int a = 0; a < 3; ++a) {
+        lo[a] = fmin(fmin(p[a], p[3 + a]), p[6 + a]);
+        hi[a] = fmax(fmax(p[a], p[3 + a]), p[6 + a]);
+    }
+    FBox b;
+    unsigned long long key = 0;
+    for (int a = 0; a < 3; ++a) {
+        b.lo[a] = __double2float_rd(lo[a] - root.centre[a] - (double)pad);
+        b.hi[a] = __double2float_ru(hi[a] - root.centre[a] + (double)pad);
+        const double ext = root.max[a] - root.min[a];
+        double q = ext > 0 ? (0.5 * (lo[a] + hi[a]) - root.min[a]) / ext : 0.0;
+        q = fmin(fmax(q, 0.0), 1.0);
+        unsigned long long c = (unsigned long long)(q * 2097151.0);
+        key |= spread21(c) << (2 - a);
+    }
+    tbox[i] = b;
+    keys[i] = key;
+    vals[i] = (unsigned)i;
+}
+
+// Karras' delta: length of the common prefix of keys i and j (ties broken by the position)
+__device__ __forceinline__ int delta(const unsigned long long* keys, int n, int i, int j) {
+    if (j < 0 || j >= n) return -1;
+    const unsigned long long a = keys[i], b = keys[j];
+    if (a == b) return 64 + __clz((unsigned)(i ^ j));
+    return __clzll((long long)(a ^ b));
+}
+
+// internal node i of the binary radix tree over the sorted keys; children: index >= 0 internal, ~leaf for a leaf
+__global__ void k_lbvh_tree(const unsigned long long* __restrict__ keys, int n, int2* __restrict__ child, int2* __restrict__ range,
+                            int* __restrict__ parent_int, int* __restrict__ parent_leaf) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+    const int dmin = delta(keys, n, i, i - d);
+    int lmax = 2;
+    while (delta(keys, n, i, i + lmax * d) > dmin) lmax *= 2;
+    int l = 0;
+    for (int t = lmax / 2; t >= 1; t /= 2)
+        if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+    const int j = i + l * d;
+    const int dnode = delta(keys, n, i, j);
+    int s = 0;
+    for (int t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+        if (t == 1) break;
+    }
+    const int gamma = i + s * d + min(d, 0);
+    const int first = min(i, j), last = max(i, j);
+    const int left = (first == gamma) ? ~gamma : gamma;
+    const int right = (last == gamma + 1) ? ~(gamma + 1) : gamma + 1;
+    child[i] = make_int2(left, right);
+    range[i] = make_int2(first, last);
+    if (left >= 0) parent_int[left] = i; else parent_leaf[~left] = i;
+    if (right >= 0) parent_int[right] = i; else parent_leaf[~right] = i;
+    if (i == 0) parent_int[0] = -1;
+}
+
+__device__ __forceinline__ FBox merge(const FBox& a, const FBox& b) {
+    FBox r;
+    for (int k = 0; k < 3; ++k) { r.lo[k] = fminf(a.lo[k], b.lo[k]); r.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+    return r;
+}
+
+// bottom-up boxes: the second thread to arrive at a node merges its children and continues upward
+__global__ void k_lbvh_boxes(int n, const unsigned int* __restrict__ order, const FBox* __restrict__ tbox, const int2* __restrict__ child,
+                             const int* __restrict__ parent_int, const int* __restrict__ parent_leaf, unsigned int* __restrict__ flags,
+                             FBox* __restrict__ nbox) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    int node = parent_leaf[p];
+    while (node >= 0) {
+        __threadfence();
+        if (atomicAdd(&flags[node], 1u) == 0u) return;            // first arrival: the sibling is not finished yet
+        __threadfence();
+        const int2 c = child[node];
+        const FBox a = c.x >= 0 ? nbox[c.x] : tbox[order[~c.x]];
+        const FBox b = c.y >= 0 ? nbox[c.y] : tbox[order[~c.y]];
+        nbox[node] = merge(a, b);
+        node = parent_int[node];
+    }
+}
+
+__global__ void k_lbvh_mark(int n, const int2* __restrict__ range, int* __restrict__ keep) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1) return;
+    keep[i] = (range[i].y - range[i].x + 1) > kLeafMax ? 1 : 0;
+}
+
+__device__ __forceinline__ void put_child(float* lo, float* hi, int32_t& c, int32_t& cn, int ch, const int2* range, const int* keep,
+                                          const int* outidx, const FBox* nbox, const FBox* tbox, const unsigned int* order) {
+    FBox b;
+    if (ch < 0) { c = ~ch; cn = 1; b = tbox[order[~ch]]; }
+    else if (!keep[ch]) { c = range[ch].x; cn = range[ch].y - range[ch].x + 1; b = nbox[ch]; }
+    else { c = outidx[ch]; cn = 0; b = nbox[ch]; }
+    for (int k = 0; k < 3; ++k) { lo[k] = b.lo[k]; hi[k] = b.hi[k]; }
+}
+
+__global__ void k_lbvh_emit(int n, const int2* __restrict__ child, const int2* __restrict__ range, const int* __restrict__ keep,
+                            const int* __restrict__ outidx, const FBox* __restrict__ nbox, const FBox* __restrict__ tbox,
+                            const unsigned int* __restrict__ order, const int* __restrict__ parent_int, BvhNode* __restrict__ out,
+                            int* __restrict__ max_depth) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n - 1 || !keep[i]) return;
+    BvhNode nd;
+    const int2 c = child[i];
+    put_child(nd.lo0, nd.hi0, nd.c0, nd.n0, c.x, range, keep, outidx, nbox, tbox, order);
+    put_child(nd.lo1, nd.hi1, nd.c1, nd.n1, c.y, range, keep, outidx, nbox, tbox, order);
+    out[outidx[i]] = nd;
+    int depth = 1;
+    for (int p = parent_int[i]; p >= 0; p = parent_int[p]) ++depth;   // every ancestor of a kept node is kept
+    atomicMax(max_depth, depth);
+}
+
+__global__ void k_lbvh_gather(int n, const unsigned int* __restrict__ order, const uint4* __restrict__ rec_in, uint4* __restrict__ rec_out,
+                              const uint4* __restrict__ slab_in, uint4* __restrict__ slab_out) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte piece per thread
+    if (t >= (long long)n * 8) return;
+    const int p = (int)(t >> 3), piece = (int)(t & 7);
+    const unsigned src = order[p];
+    rec_out[(size_t)p * 8 + piece] = rec_in[(size_t)src * 8 + piece];
+    if (piece < 4) slab_out[(size_t)p * 4 + piece] = slab_in[(size_t)src * 4 + piece];
+}
+
+struct Tmp {
+    void* p = nullptr;
+    ~Tmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, std::max<size_t>(bytes, 256)); }
+    template <class T> T* as() { return (T*)p; }
+};
+
+}  // namespace
+
+#define LB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return e__; } while (0)
+
+// d_v9: device double[n][9]; d_tris / d_slab_in: records in TriangleIndex order; outputs are caller-allocated:
+// d_nodes (>= n entries), d_btris (n), d_bslab (n).  Returns the node count and depth.
+hipError_t build_bvh_device(const double* d_v9, int n, const RootBox& root, const Rec128* d_tris, const TriSlab* d_slab_in,
+                            BvhNode* d_nodes, Rec128* d_btris, TriSlab* d_bslab, int* num_nodes, int* depth, hipStream_t stream) {
+    if (n <= kLeafMax * 2) return hipErrorInvalidValue;              // tiny scenes use the host builder
+    double ext = 0;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, root.max[a] - root.min[a]);
+    const float pad = (float)std::ldexp(ext > 0 ? ext : 1.0, -16);
+    Tmp tbox, keys, keys2, vals, vals2, sorttmp, child, range, pint, pleaf, flags, nbox, keep, outidx, scantmp, meta;
+    LB_HIP(tbox.alloc((size_t)n * sizeof(FBox)));
+    LB_HIP(keys.alloc((size_t)n * 8)); LB_HIP(keys2.alloc((size_t)n * 8));
+    LB_HIP(vals.alloc((size_t)n * 4)); LB_HIP(vals2.alloc((size_t)n * 4));
+    LB_HIP(child.alloc((size_t)n * sizeof(int2))); LB_HIP(range.alloc((size_t)n * sizeof(int2)));
+    LB_HIP(pint.alloc((size_t)n * 4)); LB_HIP(pleaf.alloc((size_t)n * 4));
+    LB_HIP(flags.alloc((size_t)n * 4)); LB_HIP(nbox.alloc((size_t)n * sizeof(FBox)));
+    LB_HIP(keep.alloc((size_t)n * 4)); LB_HIP(outidx.alloc((size_t)n * 4));
+    LB_HIP(meta.alloc(16));
+    const int T = 256, B = (n + T - 1) / T;
+    hipLaunchKernelGGL(k_lbvh_keys, dim3(B), dim3(T), 0, stream, d_v9, n, root, pad, tbox.as<FBox>(), keys.as<unsigned long long>(), vals.as<unsigned int>());
+    LB_HIP(hipGetLastError());
+    size_t sbytes = 0;
+    LB_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, sbytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(), vals.as<unsigned int>(),
+                                              vals2.as<unsigned int>(), n, 0, 63, stream));
+    LB_HIP(sorttmp.alloc(sbytes));
+    LB_HIP(hipcub::DeviceRadixSort::SortPairs(sorttmp.p, sbytes, keys.as<unsigned long long>(), keys2.as<unsigned long long>(), vals.as<unsigned int>(),
+                                              vals2.as<unsigned int>(), n, 0, 63, stream));
+    const unsigned long long* skeys = keys2.as<unsigned long long>();
+    const unsigned int* order = vals2.as<unsigned int>();
+    hipLaunchKernelGGL(k_lbvh_tree, dim3(B), dim3(T), 0, stream, skeys, n, child.as<int2>(), range.as<int2>(), pint.as<int>(), pleaf.as<int>());
+    LB_HIP(hipGetLastError());
+    LB_HIP(hipMemsetAsync(flags.p, 0, (size_t)n * 4, stream));
+    hipLaunchKernelGGL(k_lbvh_boxes, dim3(B), dim3(T), 0, stream, n, order, tbox.as<FBox>(), child.as<int2>(), pint.as<int>(), pleaf.as<int>(),
+                       flags.as<unsigned int>(), nbox.as<FBox>());
+    LB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_lbvh_mark, dim3(B), dim3(T), 0, stream, n, range.as<int2>(), keep.as<int>());
+    LB_HIP(hipGetLastError());
+    size_t cbytes = 0;
+    LB_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, cbytes, keep.as<int>(), outidx.as<int>(), n - 1, stream));
+    LB_HIP(scantmp.alloc(cbytes));
+    LB_HIP(hipcub::DeviceScan::ExclusiveSum(scantmp.p, cbytes, keep.as<int>(), outidx.as<int>(), n - 1, stream));
+    LB_HIP(hipMemsetAsync(meta.p, 0, 16, stream));
+    hipLaunchKernelGGL(k_lbvh_emit, dim3(B), dim3(T), 0, stream, n, child.as<int2>(), range.as<int2>(), keep.as<int>(), outidx.as<int>(), nbox.as<FBox>(),
+                       tbox.as<FBox>(), order, pint.as<int>(), d_nodes, meta.as<int>());
+    LB_HIP(hipGetLastError());
+    const long long pieces = (long long)n * 8;
+    hipLaunchKernelGGL(k_lbvh_gather, dim3((unsigned)((pieces + T - 1) / T)), dim3(T), 0, stream, n, order, (const uint4*)d_tris, (uint4*)d_btris,
+                       (const uint4*)d_slab_in, (uint4*)d_bslab);
+    LB_HIP(hipGetLastError());
+    // node count = keep[n-2] + outidx[n-2]; depth from the emit kernel
+    int last_keep = 0, last_idx = 0, md = 0;
+    LB_HIP(hipMemcpyAsync(&last_keep, keep.as<int>() + (n - 2), 4, hipMemcpyDeviceToHost, stream));
+    LB_HIP(hipMemcpyAsync(&last_idx, outidx.as<int>() + (n - 2), 4, hipMemcpyDeviceToHost, stream));
+    LB_HIP(hipMemcpyAsync(&md, meta.p, 4, hipMemcpyDeviceToHost, stream));
+    LB_HIP(hipStreamSynchronize(stream));
+    *num_nodes = last_keep + last_idx;
+    *depth = md + 1;                                                 // + the leaf level
+    return hipSuccess;
+}
+
+}  // namespace sr

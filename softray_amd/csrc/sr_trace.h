@@ -461,7 +461,7 @@ __device__ uint32_t soft_shadow(const DevScene& sc, const FrameConst& fc, const 
 
 // per-channel blend of two packed colours: ((s * (255 - k)) >> 8) + ((r * k) >> 8), alpha 0xFF.
 // Deliberately __noinline__ and composed with '+': inlined into the fold loop (ROCm 7.2 hipcc -O3, gfx950) the
-// middle (green) byte came out one too small -- a byte-select peephole miscompile that the GPU-vs-oracle test caught.
+// middle (green) byte came out one too small -- a byte-select peephole miscompile that the GPU-vs-CPU-checker test caught.
 __device__ __noinline__ uint32_t blend_packed(uint32_t sfc, uint32_t refl, uint32_t k) {
     uint32_t out = 255u << 24;
     const uint32_t ik = 255u - k;

@@ -315,3 +315,33 @@ def test_reflection_extension_matches_oracle():
     want, _ = o.render(f, threads=NCPU)
     got, _ = g.render(as_sr(f, sa.MODE_BVH))
     assert np.array_equal(got, want)
+
+
+def test_device_built_bvh_gives_identical_pixels():
+    """the own BVH built on the GPU (LBVH) -- any conservative BVH must give the same pixels."""
+    for n, res in ((300, 64), (20000, 128), (200000, 160)):
+        v9, argb, bmin, bmax = unit_cube_scene(n)
+        g = sa.GpuScene(0)
+        g.set_triangles(v9, argb, bmin, bmax)
+        g.build((sa.MODE_BVH,))                       # host SAH build
+        f = make_frame(res, depth=1.5, shadows=True)
+        a, _ = g.render(as_sr(f, sa.MODE_BVH))
+        rnd = orc.Random(5)
+        u = rnd.NextDoubles(6 * 20000).reshape(-1, 6)
+        starts = 3.0 * u[:, :3] - 1.5
+        dirs = (u[:, 3:] - 0.5) - starts
+        ta = g.trace(sa.MODE_BVH, starts, dirs)
+        g.build((sa.MODE_BVH,), on_device=True)       # device LBVH build replaces it
+        b, _ = g.render(as_sr(f, sa.MODE_BVH))
+        assert np.array_equal(a, b), n
+        tb = g.trace(sa.MODE_BVH, starts, dirs)
+        for key in ("hit", "tri_index", "ray_frac", "pos", "normal", "color"):
+            assert np.array_equal(ta[key], tb[key]), (n, key)
+        c, _ = g.render(as_sr(f, sa.MODE_BVH, per_lane=True))
+        assert np.array_equal(a, c)
+    # the obj.3DS golden through the device-built tree
+    g = sa.GpuScene(0)
+    g.load_3ds(open(os.path.join(GOLDEN, "obj.3ds"), "rb").read())
+    g.build((sa.MODE_BVH,), on_device=True)
+    got, _ = g.render(as_sr(make_frame(100, shadows=True), sa.MODE_BVH))
+    assert int(np.count_nonzero((got.reshape(100, 100) & 0xFFFFFF) != golden_rgb("shading_shadows", 100))) == 0
