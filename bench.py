@@ -293,6 +293,24 @@ def main():
         dt0 = (time.perf_counter() - t1) / args.steps
         out["primary_only"] = {"value": primary_rays / dt0 / 1e6, "unit": "Mrays/s", "ms_per_step": dt0 * 1e3,
                                "note": "same scene, pose and resolution with rayTraceShadows = false (shading on): primary rays only"}
+    # ---- the two surface passes of Renderer.Render() (PostProcessImage / AntiAliasImage) on the resident frame ----
+    if world == 1 and rank == 0:
+        n = args.res * args.res
+        aa_dst = torch.empty(n // 4, dtype=torch.int32, device=dev)
+        g.reset_kernel_times()
+        reps = 20
+        for _ in range(reps):
+            g.post_process_device(local.data_ptr(), n, 1, 0, stream.cuda_stream)                    # Style.ColorShuffle, in place
+            g.anti_alias_device(local.data_ptr(), args.res // 2, args.res // 2, 2, aa_dst.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        kp = g.kernel_times()
+        pp_ms = kp["k_post_process"][0] / reps
+        aa_ms = kp["k_anti_alias"][0] / reps
+        out["surface_passes"] = {
+            "post_process": {"ms": pp_ms, "achieved_GBps": 8.0 * n / (pp_ms * 1e-3) / 1e9, "bytes": "8 B/pixel (read + write in place)"},
+            "anti_alias_2x": {"ms": aa_ms, "achieved_GBps": 5.0 * n / (aa_ms * 1e-3) / 1e9, "bytes": "4 B/source pixel + 4 B/destination pixel"},
+            "peak_GBps": 8000.0,
+        }
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

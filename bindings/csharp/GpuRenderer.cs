@@ -47,6 +47,8 @@ namespace Engine3D.Hip
         [DllImport(Lib)] public static extern int sr_tree_stats(IntPtr scene, [Out] int[] out4);
         [DllImport(Lib)] public static extern int sr_render(IntPtr scene, ref SrFrame frame, [In, Out] int[] pixels, [Out] ulong[] stats4);
         [DllImport(Lib)] public static extern int sr_load_3ds(IntPtr scene, byte[] data, UIntPtr len);
+        [DllImport(Lib)] public static extern int sr_post_process(IntPtr scene, [In, Out] int[] pixels, long count, int style, uint backgroundColor);
+        [DllImport(Lib)] public static extern int sr_anti_alias(IntPtr scene, [In] int[] src, int dstWidth, int dstHeight, int resolution, [In, Out] int[] dst);
         [DllImport(Lib)] public static extern IntPtr sr_last_error();
         public static string LastError() { return Marshal.PtrToStringAnsi(sr_last_error()); }
 
@@ -129,6 +131,18 @@ namespace Engine3D.Hip
             };
             for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { f.transform[4 * r + c] = transform[r, c]; f.inv_transform[4 * r + c] = inverseTransform[r, c]; }
             Native.Check(Native.sr_render(scene, ref f, pixels, stats4));      // blocking; `pixels` is only touched during the call
+        }
+
+        /// PostProcessImage's colour functions (Renderer.cs:819-865): style = (int)Renderer.Style for Standard..DepthBanded.
+        public void PostProcess(int[] pixels, int style, uint backgroundColor)
+        {
+            Native.Check(Native.sr_post_process(scene, pixels, pixels.LongLength, style, backgroundColor));
+        }
+
+        /// AntiAliasImage (Renderer.cs:937-978): surface.Pixels (dstWidth*res x dstHeight*res) -> antiAliasedSurface.Pixels.
+        public void AntiAlias(int[] src, int dstWidth, int dstHeight, int resolution, int[] dst)
+        {
+            Native.Check(Native.sr_anti_alias(scene, src, dstWidth, dstHeight, resolution, dst));
         }
 
         public void Dispose()

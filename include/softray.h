@@ -210,6 +210,27 @@ int  sr_last_ray_stats(const sr_scene*, uint64_t out[12]);
 void sr_make_random_triangles(int32_t seed, int64_t n, double space, double extent, double origin, int32_t opaque,
                               double* v9, uint32_t* argb);
 
+/* ---- surface passes that Renderer.Render() runs after the raytrace (Engine3D/Renderer.cs:765-767) ----
+ * sr_post_process[_device]  = PostProcessImage's per-pixel colour functions (Renderer.cs:819-865, Surface.ApplyColorFunc
+ *   Surface.cs:226-233), applied in place to `count` pixels.  `background_color` is Renderer.BackgroundColor (alpha
+ *   masked off, Renderer.cs:304-320) and is only read by SR_STYLE_NEGATIVE.  The two depth styles are the reference's
+ *   8-bit-alpha-depth twizzles (taken when depthBuffer && !depthBufferHires; the host decides).  Style.Normals reads the
+ *   rasteriser's depth buffer and is outside the raytrace path: SR_ERR_UNSUPPORTED.
+ * sr_anti_alias[_device]    = AntiAliasImage (Renderer.cs:937-978): src is (dst_width*resolution) x (dst_height*resolution),
+ *   every destination pixel is the integer average of its resolution^2 source pixels per channel, alpha 255. */
+enum {
+    SR_STYLE_STANDARD = 0,       /* Style.Standard: nothing to do */
+    SR_STYLE_COLOR_SHUFFLE = 1,  /* ZRGB -> 0GBR */
+    SR_STYLE_NEGATIVE = 2,
+    SR_STYLE_DEPTH_SMOOTH = 3,   /* ZRGB -> 0ZZZ */
+    SR_STYLE_DEPTH_BANDED = 4    /* Z * 111 */
+};
+int  sr_post_process(sr_scene*, int32_t* pixels, int64_t count, int32_t style, uint32_t background_color);
+int  sr_post_process_device(sr_scene*, void* d_pixels, int64_t count, int32_t style, uint32_t background_color, void* hip_stream);
+int  sr_anti_alias(sr_scene*, const int32_t* src, int32_t dst_width, int32_t dst_height, int32_t resolution, int32_t* dst);
+int  sr_anti_alias_device(sr_scene*, const void* d_src, int32_t dst_width, int32_t dst_height, int32_t resolution, void* d_dst,
+                          void* hip_stream);
+
 /* Diagnostics only: the pipeline's device counters after the last row band of the last frame
  * {hit points queued, per-lane shadow work head, hit points that needed the long (round-2) candidate list,
  *  hit points sent to the exact per-lane fallback, fallback work head, 0, 0, 0}. */

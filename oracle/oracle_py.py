@@ -232,3 +232,40 @@ class Scene:
         if counters:
             res["counters"] = cnt
         return res
+
+
+# ---- surface passes after the raytrace (numpy restatement; Engine3D/Renderer.cs:765-767) ----
+STYLE_STANDARD, STYLE_COLOR_SHUFFLE, STYLE_NEGATIVE, STYLE_DEPTH_SMOOTH, STYLE_DEPTH_BANDED = 0, 1, 2, 3, 4
+
+
+def post_process(pixels, style, background_color=0):
+    """PostProcessImage's Surface.ApplyColorFunc lambdas (Renderer.cs:819-865, Surface.cs:226-233) on a
+    uint32 array; C# unchecked uint arithmetic = numpy uint32 wrap-around."""
+    x = np.ascontiguousarray(pixels).view(np.uint32).copy()
+    bg = np.uint32(background_color)
+    if style == STYLE_STANDARD:
+        return x
+    if style == STYLE_COLOR_SHUFFLE:                                   # :827-830
+        return ((x & np.uint32(0xffff)) << np.uint32(8)) + ((x >> np.uint32(16)) & np.uint32(0xff))
+    if style == STYLE_NEGATIVE:                                        # :832-834
+        with np.errstate(over="ignore"):
+            neg = np.uint32(0x00ffffff) - x
+        return np.where(x == bg, bg, neg).astype(np.uint32)
+    if style == STYLE_DEPTH_SMOOTH:                                    # :844-848
+        return (((x >> np.uint32(8)) & np.uint32(0xff0000)) + ((x >> np.uint32(16)) & np.uint32(0xff00))
+                + ((x >> np.uint32(24)) & np.uint32(0xff)))
+    if style == STYLE_DEPTH_BANDED:                                    # :859-863
+        return ((x >> np.uint32(24)) & np.uint32(0xff)) * np.uint32(111)
+    raise ValueError("style %r is not a per-pixel colour function" % (style,))
+
+
+def anti_alias(src, dst_width, dst_height, resolution):
+    """AntiAliasImage (Renderer.cs:937-978): integer average of resolution^2 source pixels per channel,
+    PackRgb (alpha 255, Surface.cs:98-101)."""
+    n = int(resolution)
+    s = np.ascontiguousarray(src).view(np.uint32).reshape(dst_height, n, dst_width, n).astype(np.int64)
+    out = np.full((dst_height, dst_width), 255 << 24, dtype=np.int64)
+    for shift in (16, 8, 0):
+        chan = ((s >> shift) & 0xff).sum(axis=(1, 3)) // (n * n)
+        out += (chan & 0xff) << shift
+    return out.astype(np.uint32).reshape(-1)

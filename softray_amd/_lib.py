@@ -20,6 +20,7 @@ F_PER_LANE_SHADOWS = 1 << 9
 MODE_REF_TREE, MODE_BRUTE, MODE_BVH = 0, 1, 2
 TARGET_ROOT = 0x100
 BUILD_ON_DEVICE = 0x100
+STYLE_STANDARD, STYLE_COLOR_SHUFFLE, STYLE_NEGATIVE, STYLE_DEPTH_SMOOTH, STYLE_DEPTH_BANDED = 0, 1, 2, 3, 4
 
 # every symbol include/softray.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = [
@@ -27,6 +28,7 @@ SYMBOLS = [
     "sr_render", "sr_render_device", "sr_frame_pixel_count", "sr_trace_rays", "sr_instance_matrices",
     "sr_default_fov_depth", "sr_area_light_offsets", "sr_load_3ds", "sr_num_triangles", "sr_get_triangles",
     "sr_reset_kernel_times", "sr_kernel_times", "sr_last_ray_stats", "sr_make_random_triangles", "sr_debug_counters", "sr_last_error", "sr_abi_version",
+    "sr_post_process", "sr_post_process_device", "sr_anti_alias", "sr_anti_alias_device",
 ]
 
 
@@ -83,6 +85,12 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("libsoftray_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(softray_amd has no CPU/Python implementation of the raytrace path)")
+    try:
+        # torch ships its own libamdhip64; loading it first makes this library bind to the same HIP runtime, so that
+        # device pointers and streams can be shared (two runtimes in one process do not see each other's GPU state)
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, u32, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_double
     L.sr_create.restype = i32; L.sr_create.argtypes = [i32, C.POINTER(vp)]
@@ -107,6 +115,10 @@ def lib():
     L.sr_make_random_triangles.restype = None
     L.sr_make_random_triangles.argtypes = [i32, i64, dbl, dbl, dbl, i32, vp, vp]
     L.sr_debug_counters.restype = i32; L.sr_debug_counters.argtypes = [vp, vp]
+    L.sr_post_process.restype = i32; L.sr_post_process.argtypes = [vp, vp, i64, i32, u32]
+    L.sr_post_process_device.restype = i32; L.sr_post_process_device.argtypes = [vp, vp, i64, i32, u32, vp]
+    L.sr_anti_alias.restype = i32; L.sr_anti_alias.argtypes = [vp, vp, i32, i32, i32, vp]
+    L.sr_anti_alias_device.restype = i32; L.sr_anti_alias_device.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.sr_last_error.restype = C.c_char_p; L.sr_last_error.argtypes = []
     L.sr_abi_version.restype = i32; L.sr_abi_version.argtypes = []
     _lib = L

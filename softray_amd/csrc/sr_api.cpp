@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -73,7 +74,7 @@ struct sr_scene {
     size_t      bvh_num_nodes = 0;
     // device state
     DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab;
-    DBuf d_offsets, d_rowmap, d_pixels, d_stats, d_io[9], d_hits, d_samples, d_counters, d_fallback, d_rlist[sr::kShaftRounds], d_rstate[sr::kShaftRounds], d_rcount[sr::kShaftRounds], d_rcand[sr::kShaftRounds];
+    DBuf d_offsets, d_rowmap, d_pixels, d_aa, d_stats, d_io[9], d_hits, d_samples, d_counters, d_fallback, d_rlist[sr::kShaftRounds], d_rstate[sr::kShaftRounds], d_rcount[sr::kShaftRounds], d_rcand[sr::kShaftRounds];
     int num_cus = 0;
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
     std::vector<double>  offsets_host;
@@ -359,7 +360,7 @@ void sr_destroy(sr_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
-                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_fallback};
+                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_fallback};
         for (DBuf* b : bufs) b->release();
         for (int r = 0; r < sr::kShaftRounds; ++r) { s->d_rlist[r].release(); s->d_rstate[r].release(); s->d_rcount[r].release(); s->d_rcand[r].release(); }
         for (DBuf& b : s->d_io) b.release();
@@ -605,6 +606,68 @@ void sr_make_random_triangles(int32_t seed, int64_t n, double space, double exte
         uint32_t c = (uint32_t)rnd.next();                                              // (uint)random.Next()
         argb[i] = opaque ? (0xFF000000u | (c & 0xFFFFFFu)) : c;
     }
+}
+
+// ---- surface passes, Renderer.cs:765-767 ----
+int sr_post_process_device(sr_scene* s, void* d_pixels, int64_t count, int32_t style, uint32_t background_color, void* hip_stream) {
+    if (!s || count < 0 || (count > 0 && !d_pixels)) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_post_process");
+    if (style < SR_STYLE_STANDARD || style > SR_STYLE_DEPTH_BANDED)
+        return fail(SR_ERR_UNSUPPORTED, "render style " + std::to_string(style) + " is not a per-pixel colour function (Style.Normals needs the rasteriser's depth buffer)");
+    int rc = use_device(s);
+    if (rc) return rc;
+    if (style == SR_STYLE_STANDARD || count == 0) return SR_OK;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    hipEvent_t e0, e1;
+    if ((rc = next_events(s, sr::K_POST, e0, e1))) return rc;
+    if (e0) SR_HIP(hipEventRecord(e0, stream));
+    SR_HIP(sr::launch_post_process((uint32_t*)d_pixels, count, style, background_color, s->num_cus, stream));
+    if (e1) SR_HIP(hipEventRecord(e1, stream));
+    return SR_OK;
+}
+
+int sr_post_process(sr_scene* s, int32_t* pixels, int64_t count, int32_t style, uint32_t background_color) {
+    if (!s || count < 0 || (count > 0 && !pixels)) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_post_process");
+    if (style < SR_STYLE_STANDARD || style > SR_STYLE_DEPTH_BANDED)
+        return fail(SR_ERR_UNSUPPORTED, "render style " + std::to_string(style) + " is not a per-pixel colour function (Style.Normals needs the rasteriser's depth buffer)");
+    int rc = use_device(s);
+    if (rc) return rc;
+    if (style == SR_STYLE_STANDARD || count == 0) return SR_OK;
+    SR_HIP(s->d_pixels.reserve((size_t)count * 4));
+    SR_HIP(hipMemcpy(s->d_pixels.p, pixels, (size_t)count * 4, hipMemcpyHostToDevice));
+    if ((rc = sr_post_process_device(s, s->d_pixels.p, count, style, background_color, nullptr))) return rc;
+    SR_HIP(hipMemcpy(pixels, s->d_pixels.p, (size_t)count * 4, hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
+int sr_anti_alias_device(sr_scene* s, const void* d_src, int32_t dst_width, int32_t dst_height, int32_t resolution, void* d_dst, void* hip_stream) {
+    if (!s || !d_src || !d_dst || dst_width <= 0 || dst_height <= 0) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_anti_alias");
+    if (resolution < 1 || resolution > 64 || (int64_t)dst_width * resolution > INT_MAX || (int64_t)dst_height * resolution > INT_MAX)
+        return fail(SR_ERR_INVALID_ARG, "AntiAliasResolution must be in 1..64");           // Renderer.cs:374 (> 0)
+    int rc = use_device(s);
+    if (rc) return rc;
+    hipStream_t stream = (hipStream_t)hip_stream;
+    hipEvent_t e0, e1;
+    if ((rc = next_events(s, sr::K_ANTI_ALIAS, e0, e1))) return rc;
+    if (e0) SR_HIP(hipEventRecord(e0, stream));
+    SR_HIP(sr::launch_anti_alias((const uint32_t*)d_src, (uint32_t*)d_dst, dst_width, dst_height, resolution, stream));
+    if (e1) SR_HIP(hipEventRecord(e1, stream));
+    return SR_OK;
+}
+
+int sr_anti_alias(sr_scene* s, const int32_t* src, int32_t dst_width, int32_t dst_height, int32_t resolution, int32_t* dst) {
+    if (!s || !src || !dst || dst_width <= 0 || dst_height <= 0) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_anti_alias");
+    if (resolution < 1 || resolution > 64 || (int64_t)dst_width * resolution > INT_MAX || (int64_t)dst_height * resolution > INT_MAX)
+        return fail(SR_ERR_INVALID_ARG, "AntiAliasResolution must be in 1..64");
+    int rc = use_device(s);
+    if (rc) return rc;
+    const size_t dst_bytes = (size_t)dst_width * dst_height * 4;
+    const size_t src_bytes = dst_bytes * resolution * resolution;
+    SR_HIP(s->d_pixels.reserve(src_bytes));
+    SR_HIP(s->d_aa.reserve(dst_bytes));
+    SR_HIP(hipMemcpy(s->d_pixels.p, src, src_bytes, hipMemcpyHostToDevice));
+    if ((rc = sr_anti_alias_device(s, s->d_pixels.p, dst_width, dst_height, resolution, s->d_aa.p, nullptr))) return rc;
+    SR_HIP(hipMemcpy(dst, s->d_aa.p, dst_bytes, hipMemcpyDeviceToHost));
+    return SR_OK;
 }
 
 int sr_debug_counters(sr_scene* s, uint32_t out[8]) {

@@ -28,7 +28,7 @@ struct DevScene {
 };
 
 constexpr int kShaftRounds = 2;
-enum KernelId { K_RENDER = 0, K_TRACE = 1, K_PRIMARY = 2, K_SHADOW = 3, K_RESOLVE = 4, K_SHAFT = 5, K_FALLBACK = 6, K_SHAFT2 = 7, K_SHADOW2 = 8, K_COUNT = 9 };
+enum KernelId { K_RENDER = 0, K_TRACE = 1, K_PRIMARY = 2, K_SHADOW = 3, K_RESOLVE = 4, K_SHAFT = 5, K_FALLBACK = 6, K_SHAFT2 = 7, K_SHADOW2 = 8, K_POST = 9, K_ANTI_ALIAS = 10, K_COUNT = 11 };
 const char* kernel_name(int id);
 
 struct RenderLaunch {
@@ -80,6 +80,10 @@ size_t pipeline_round_state_bytes();
 // Own BVH built on the device (sr_lbvh.hip).  Inputs in TriangleIndex order, outputs caller-allocated (n entries each).
 hipError_t build_bvh_device(const double* d_v9, int n, const RootBox& root, const Rec128* d_tris, const TriSlab* d_slab_in,
                             BvhNode* d_nodes, Rec128* d_btris, TriSlab* d_bslab, int* num_nodes, int* depth, hipStream_t stream);
+
+// Surface passes (sr_post.hip): PostProcessImage colour functions and AntiAliasImage, Renderer.cs:819-978.
+hipError_t launch_post_process(uint32_t* d_pixels, long long count, int style, uint32_t background, int num_cus, hipStream_t stream);
+hipError_t launch_anti_alias(const uint32_t* d_src, uint32_t* d_dst, int dst_w, int dst_h, int res, hipStream_t stream);
 
 struct TraceLaunch {
     DevScene sc;

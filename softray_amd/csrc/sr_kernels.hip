@@ -161,6 +161,8 @@ const char* kernel_name(int id) {
         case K_FALLBACK: return "k_shadow_fallback";
         case K_SHAFT2: return "k_shaft_round2";
         case K_SHADOW2: return "k_shadow_round2";
+        case K_POST: return "k_post_process";
+        case K_ANTI_ALIAS: return "k_anti_alias";
         default: return "?";
     }
 }

@@ -156,7 +156,10 @@ public:
 
 class Renderer {
 public:
+    enum class Style { Standard, ColorShuffle, Negative, DepthSmooth, DepthBanded, Normals, Count };   // Renderer.cs:23-33
     // ---- public fields, Renderer.cs:35-139 ----
+    Style RenderStyle = Style::Standard;
+    bool depthBuffer = false, depthBufferHires = false;    // only steer the two depth styles here (:837-863)
     double ambientLight_intensity = 0.1;
     Vector directionalLight_dir, positionalLight_pos;
     double specularLight_shininess = 100.0;
@@ -196,11 +199,38 @@ public:
         if (modelVolatile_) { modelVolatile_->LoadingComplete = true; modelVolatile_->LoadingError = false; }
     }
 
+    int AntiAliasResolution() const { return antiAliasResolution_; }
+    void AntiAliasResolution(int value) {                  // Renderer.cs:366-413
+        if (value <= 0) throw std::invalid_argument("AntiAliasResolution must be greater than zero");
+        if (value == antiAliasResolution_) return;
+        int w = aaPixels_ ? aaWidth_ : width_, h = aaPixels_ ? aaHeight_ : height_;
+        int32_t* pixels = aaPixels_ ? aaPixels_ : pixels_;   // restore the original surface
+        antiAliasResolution_ = value;
+        if (value == 1) {
+            aaPixels_ = nullptr;
+            hires_.clear();
+        } else {
+            aaPixels_ = pixels; aaWidth_ = w; aaHeight_ = h;
+            w *= value; h *= value;
+            hires_.assign((size_t)w * h, 0);               // larger surface for pre-anti-aliased rendering
+            pixels = hires_.data();
+        }
+        SetSurface(w, h, pixels);
+    }
     // caller owns `pixels` (int[width*height]); written in place (Renderer.cs:593-626)
     void SetRenderingSurface(int width, int height, int32_t* pixels) {
-        bool same = width == width_ && height == height_;
-        pixels_ = pixels;
-        if (!same) { width_ = width; height_ = height; rayTraceStartRow = 0; rayTraceEndRow = height - 1; }
+        const int n = antiAliasResolution_;
+        if (width * n == width_ && height * n == height_) {   // unchanged resolution: swap the buffer only
+            if (n > 1) aaPixels_ = pixels; else pixels_ = pixels;
+            return;
+        }
+        if (n > 1) {
+            aaPixels_ = pixels; aaWidth_ = width; aaHeight_ = height;
+            width *= n; height *= n;
+            hires_.assign((size_t)width * height, 0);
+            pixels = hires_.data();
+        }
+        SetSurface(width, height, pixels);
     }
     void Load3dsModelFromStream(std::istream& stream) {    // Renderer.cs:629-635
         modelVolatile_ = std::make_shared<Engine3D::Model>();
@@ -230,6 +260,8 @@ public:
             inst->FieldOfViewDepth = fieldOfViewDepth_;    // :749
             RaytraceGeometry(*inst);
         }
+        PostProcessImage();                                // :765
+        AntiAliasImage();                                  // :767
     }
     // Renderer.cs:465-504
     int64_t NumRaysFired() const { return (int64_t)stats_[0]; }
@@ -261,6 +293,23 @@ public:
     }
 
 private:
+    void SetSurface(int width, int height, int32_t* pixels) {   // Renderer.cs:617-626
+        pixels_ = pixels; width_ = width; height_ = height;
+        rayTraceStartRow = 0; rayTraceEndRow = height - 1;
+    }
+    void PostProcessImage() {                              // Renderer.cs:819-897
+        if ((RenderStyle == Style::DepthSmooth || RenderStyle == Style::DepthBanded) && (depthBufferHires || !depthBuffer)) return;
+        if (RenderStyle == Style::Normals) {
+            if (depthBuffer || depthBufferHires) throw std::logic_error("Style.Normals reads the rasteriser's depth buffer (out of scope)");
+            return;
+        }
+        if (RenderStyle != Style::Standard)
+            sr_check(sr_post_process(scene_, pixels_, (int64_t)width_ * height_, (int32_t)RenderStyle, backgroundColor_));
+    }
+    void AntiAliasImage() {                                // Renderer.cs:937-978
+        if (antiAliasResolution_ < 2) return;
+        sr_check(sr_anti_alias(scene_, pixels_, aaWidth_, aaHeight_, antiAliasResolution_, aaPixels_));
+    }
     int Mode() const { return gpuTraceMode >= 0 ? gpuTraceMode : (rayTraceSubdivision ? SR_MODE_REF_TREE : SR_MODE_BRUTE); }
     bool PinModel() {                                      // Renderer.cs:791-810
         if (!modelVolatile_) return false;
@@ -283,6 +332,10 @@ private:
     double fieldOfViewDepth_ = 0;
     int width_ = 1, height_ = 1;
     int32_t* pixels_ = nullptr;
+    int antiAliasResolution_ = 1;                          // Renderer.cs:155-156
+    int aaWidth_ = 0, aaHeight_ = 0;
+    int32_t* aaPixels_ = nullptr;                          // antiAliasedSurface: the caller's buffer while AA > 1
+    std::vector<int32_t> hires_;
     std::shared_ptr<Engine3D::Model> modelVolatile_, model_;
     const Engine3D::Model* sceneModel_ = nullptr;
     uint32_t built_ = 0;

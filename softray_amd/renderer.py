@@ -173,10 +173,20 @@ class Instance:
         self.Yaw, self.Pitch, self.Roll = Yaw, Pitch, Roll
 
 
+class Style:
+    """Renderer.Style (Renderer.cs:23-33): "style of rendering (actually post-processing)"."""
+    Standard, ColorShuffle, Negative, DepthSmooth, DepthBanded, Normals, Count = range(7)
+
+
 class Renderer:
     """Engine3D.Renderer, raytrace half.  Public fields keep the C# names (Renderer.cs:35-139)."""
 
+    Style = Style
+
     def __init__(self, device=0):
+        self.RenderStyle = Style.Standard                          # Renderer.cs:35
+        self.depthBuffer = False                                   # Renderer.cs:56-57 (only steer the two depth styles here)
+        self.depthBufferHires = False
         # lighting (view space), Renderer.cs:207-217
         self.ambientLight_intensity = 0.1
         d = Vector(-1, -1, 1)
@@ -217,6 +227,8 @@ class Renderer:
         self._fieldOfViewDepth = default_fov_depth()               # Renderer.cs:97-101
         self._width = self._height = 1
         self._pixels = np.zeros(1, dtype=np.int32)
+        self._antiAliasResolution = 1                              # Renderer.cs:155-156
+        self._aaSurface = None                                     # (width, height, pixels) of antiAliasedSurface
         self._modelVolatile = None
         self._model = None
         self._scene = GpuScene(device)
@@ -237,6 +249,30 @@ class Renderer:
     @property
     def BackgroundColorWithAlpha(self):
         return self._backgroundColor | 0xFF000000
+
+    @property
+    def AntiAliasResolution(self):
+        return self._antiAliasResolution
+
+    @AntiAliasResolution.setter
+    def AntiAliasResolution(self, value):                          # Renderer.cs:366-413
+        value = int(value)
+        if value <= 0:
+            raise ValueError("AntiAliasResolution must be greater than zero")
+        if value == self._antiAliasResolution:
+            return
+        if self._aaSurface is not None:                            # restore the original surface
+            w, h, pixels = self._aaSurface
+        else:
+            w, h, pixels = self._width, self._height, self._pixels
+        self._antiAliasResolution = value
+        if value == 1:
+            self._aaSurface = None
+        else:
+            self._aaSurface = (w, h, pixels)
+            w, h = w * value, h * value
+            pixels = np.zeros(w * h, dtype=np.int32)               # larger surface for pre-anti-aliased rendering
+        self._SetSurface(w, h, pixels)
 
     @property
     def Model(self):
@@ -262,12 +298,24 @@ class Renderer:
         pixels = np.asarray(pixels)
         if pixels.dtype != np.int32 or pixels.size < width * height or not pixels.flags["C_CONTIGUOUS"]:
             raise ValueError("pixels must be a contiguous int32 array of at least width*height elements")
-        same = (width == self._width and height == self._height)
+        n = self._antiAliasResolution
+        if width * n == self._width and height * n == self._height:    # resolution unchanged: swap the buffer only
+            if n > 1:
+                self._aaSurface = (width, height, pixels)
+            else:
+                self._pixels = pixels
+            return
+        if n > 1:
+            self._aaSurface = (width, height, pixels)
+            width, height = width * n, height * n
+            pixels = np.zeros(width * height, dtype=np.int32)
+        self._SetSurface(width, height, pixels)
+
+    def _SetSurface(self, width, height, pixels):                  # Renderer.cs:617-626
         self._pixels = pixels
-        if not same:
-            self._width, self._height = width, height
-            self.rayTraceStartRow = 0
-            self.rayTraceEndRow = height - 1
+        self._width, self._height = width, height
+        self.rayTraceStartRow = 0
+        self.rayTraceEndRow = height - 1
 
     def Load3dsModelFromStream(self, stream):                      # Renderer.cs:629-635
         self._modelVolatile = Model()
@@ -321,6 +369,26 @@ class Renderer:
         for instance in self.Instances:
             instance.FieldOfViewDepth = self._fieldOfViewDepth     # Renderer.cs:749
             self._RaytraceGeometry(instance)
+        self._PostProcessImage()                                   # Renderer.cs:765
+        self._AntiAliasImage()                                     # Renderer.cs:767
+
+    def _PostProcessImage(self):                                   # Renderer.cs:819-897
+        style = self.RenderStyle
+        if style in (Style.DepthSmooth, Style.DepthBanded) and (self.depthBufferHires or not self.depthBuffer):
+            return                                                 # hires branch is a TODO in the reference, :837-842
+        if style == Style.Normals:
+            if self.depthBuffer or self.depthBufferHires:
+                raise NotImplementedError("Style.Normals reads the rasteriser's depth buffer (out of scope, SURVEY.md 2 row 21)")
+            return
+        if style != Style.Standard:
+            self._scene.post_process(self._pixels.reshape(-1), style, self._backgroundColor)   # every pixel of the surface array
+
+    def _AntiAliasImage(self):                                     # Renderer.cs:937-978
+        if self._antiAliasResolution < 2:
+            return
+        w, h, pixels = self._aaSurface
+        self._scene.anti_alias(self._pixels.reshape(-1)[: self._width * self._height], w, h, self._antiAliasResolution,
+                               out=pixels.reshape(-1)[: w * h])
 
     def Dispose(self):                                             # Renderer.cs:236-256
         if self._scene is not None:
@@ -388,5 +456,5 @@ class Renderer:
         _, self._stats = self._scene.render(frame, out=view, stats=True)
 
 
-__all__ = ["Renderer", "Instance", "Model", "GeometryCollection", "Sphere", "Plane", "Triangle", "Vector", "Color",
+__all__ = ["Renderer", "Style", "Instance", "Model", "GeometryCollection", "Sphere", "Plane", "Triangle", "Vector", "Color",
            "MODE_REF_TREE", "MODE_BRUTE", "MODE_BVH"]

@@ -94,6 +94,28 @@ class GpuScene:
         _check(_lib.lib().sr_render_device(self._h, C.byref(frame), C.c_void_p(d_pixels_ptr), C.c_void_p(stream),
                                            C.c_void_p(d_stats_ptr) if d_stats_ptr else None))
 
+    # ---- PostProcessImage / AntiAliasImage (Renderer.cs:765-767) ----
+    def post_process(self, pixels, style, background_color=0):
+        """In place on a host int32/uint32 array."""
+        assert pixels.dtype.itemsize == 4 and pixels.flags["C_CONTIGUOUS"]
+        _check(_lib.lib().sr_post_process(self._h, _p(pixels), pixels.size, int(style), int(background_color) & 0xFFFFFFFF))
+        return pixels
+
+    def post_process_device(self, d_pixels_ptr, count, style, background_color=0, stream=0):
+        _check(_lib.lib().sr_post_process_device(self._h, C.c_void_p(d_pixels_ptr), int(count), int(style),
+                                                 int(background_color) & 0xFFFFFFFF, C.c_void_p(stream)))
+
+    def anti_alias(self, src, dst_width, dst_height, resolution, out=None):
+        src = np.ascontiguousarray(src)
+        assert src.dtype.itemsize == 4 and (resolution < 1 or src.size == dst_width * dst_height * resolution * resolution)
+        dst = out if out is not None else np.zeros(dst_width * dst_height, dtype=np.int32)
+        _check(_lib.lib().sr_anti_alias(self._h, _p(src), int(dst_width), int(dst_height), int(resolution), _p(dst)))
+        return dst.view(np.uint32)
+
+    def anti_alias_device(self, d_src_ptr, dst_width, dst_height, resolution, d_dst_ptr, stream=0):
+        _check(_lib.lib().sr_anti_alias_device(self._h, C.c_void_p(d_src_ptr), int(dst_width), int(dst_height), int(resolution),
+                                               C.c_void_p(d_dst_ptr), C.c_void_p(stream)))
+
     def ray_stats(self):
         """primary {rays, tests, nodes, leaves} + secondary {rays, tests, nodes, leaves} of the last render(stats=True)."""
         out = np.zeros(12, dtype=np.uint64)

@@ -72,6 +72,41 @@ static int RaytraceScenario(const std::string& dir, bool shading, bool focalBlur
     return diff == 0 ? 0 : 1;
 }
 
+// Render() = raytrace + PostProcessImage + AntiAliasImage (Renderer.cs:746-767): the Negative style at AntiAliasResolution 2
+// must equal the Standard 200x200 frame pushed through the two passes restated here with plain loops.
+static int StyleAndAntiAliasScenario(const std::string& dir) {
+    std::vector<int32_t> hires(200 * 200), user(100 * 100, 0);
+    {
+        Renderer r(0);
+        RendererSetup(r, dir + "/obj.3ds", -22.0, 135.0, 0.0, 1.0, 200);
+        r.SetRenderingSurface(200, 200, hires.data());
+        r.rayTrace = true; r.rayTraceFocalBlur = false;
+        r.Render();
+    }
+    Renderer r(0);
+    RendererSetup(r, dir + "/obj.3ds", -22.0, 135.0, 0.0, 1.0, 100);
+    r.SetRenderingSurface(100, 100, user.data());
+    r.AntiAliasResolution(2);
+    r.RenderStyle = Renderer::Style::Negative;
+    r.rayTrace = true; r.rayTraceFocalBlur = false;
+    r.Render();
+    int diff = 0;
+    for (int y = 0; y < 100; ++y)
+        for (int x = 0; x < 100; ++x) {
+            int sum[3] = {0, 0, 0};
+            for (int sy = 0; sy < 2; ++sy)
+                for (int sx = 0; sx < 2; ++sx) {
+                    uint32_t c = (uint32_t)hires[(size_t)(2 * y + sy) * 200 + 2 * x + sx];
+                    c = (c == 0x00ff00ffu) ? 0x00ff00ffu : 0x00ffffffu - c;          // Renderer.cs:832-834
+                    sum[0] += (c >> 16) & 0xff; sum[1] += (c >> 8) & 0xff; sum[2] += c & 0xff;
+                }
+            uint32_t want = (255u << 24) + ((uint32_t)(sum[0] / 4) << 16) + ((uint32_t)(sum[1] / 4) << 8) + (uint32_t)(sum[2] / 4);
+            if ((uint32_t)user[(size_t)y * 100 + x] != want) ++diff;
+        }
+    std::printf("%-36s 100x100 diff=%d (AntiAliasResolution 2, Style.Negative)\n", "negative_2xAntiAliasResolution", diff);
+    return diff == 0 ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: %s <golden-dir>\n", argv[0]); return 2; }
     std::string dir = argv[1];
@@ -86,6 +121,7 @@ int main(int argc, char** argv) {
         bad += RaytraceScenario(dir, true, true, true, 4, 50);          // RaytraceShadowAndFocalBlur (:179-188)
         bad += RaytraceScenario(dir, true, false, true, 4, 50);         // RaytraceShadowAndAntiAlias (:207-213)
         bad += RaytraceScenario(dir, true, true, false, 2, 100);
+        bad += StyleAndAntiAliasScenario(dir);
         // error behaviour: Render() without a model draws nothing (Renderer.cs:736-739)
         { Renderer r(0); r.rayTrace = true; r.SetRenderingSurface(4, 4, pixels.data()); r.Render(); }
         // FormatException for a non-3DS stream (ThreeDSFile.cs:166-169)
