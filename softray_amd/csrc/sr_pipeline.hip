@@ -260,7 +260,7 @@ __device__ __forceinline__ bool prepare_sample(const DevScene& sc, D3 rs, D3 rd,
     D3 end = rs + rd * 10000.0;
     r.s = rs;
     r.d = rd;
-    if (!clip_segment(sc.root, r.s, end)) return false;
+    if (!clip_segment<false>(sc.root, r.s, end)) return false;
     r.offset = length(rs - r.s) / length(rd);
     return true;
 }
@@ -569,6 +569,9 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
             r0[pass] = make_uint4(0, 0, 0, 0);
             if (slot < n0) r0[pass] = reinterpret_cast<const uint4*>(&sc.btris[e])[lane & 7];
         }
+        // the pixel's shaded colour is needed only when the item is finished: fetch it now, off the critical path
+        uint32_t shaded = 0;
+        if (lane == 0) shaded = samples[rec.sample];
         // ---- (b) prefetch the next item ----
         {
             const unsigned int sn = slot_i + nwaves, snn = sn + nwaves;
@@ -599,10 +602,16 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                 bool blocked = false;
                 if (EXTRA) blocked = extras_block<EXTRA>(sc, rs, rd, sec);
                 if (blocked) escaped[k] = false;
-                else if (work) alive[k] = prepare_sample(sc, rs, rd, ray[k]);   // outside the root box: nothing can block it
+                else if (work && fc.debug != 22 && fc.debug != 23) alive[k] = prepare_sample(sc, rs, rd, ray[k]);   // outside the root box: nothing can block it
             }
         }
         bool have = __any(alive[0] || alive[1]);
+        if (fc.debug == 24) have = false;                  // timing experiment: clip only
+        // rcur: the chunk about to be staged (the first one was requested before the clip); while a chunk is being
+        // tested, the next chunk's records are already on their way (requested right after the LDS write)
+        uint4 rcur[kRecordsPerPass / 8];
+#pragma unroll
+        for (int pass = 0; pass < kRecordsPerPass / 8; ++pass) rcur[pass] = r0[pass];
         for (int base = 0; base < ntri && have; base += kRecordsPerPass) {
             const int npass = min(kRecordsPerPass, ntri - base);
             sec.nodes += (uint32_t)npass;
@@ -610,18 +619,22 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
 #pragma unroll
             for (int pass = 0; pass < kRecordsPerPass / 8; ++pass) {
                 const int slot = pass * 8 + (lane >> 3);
-                if (base == 0) {
-                    if (slot < npass) wrec[slot * 8 + (lane & 7)] = r0[pass];
-                } else {
-                    const int32_t es = __shfl(ent, (base + slot) & 63, 64);   // all lanes take part in the shuffle
-                    if (slot < npass) {
-                        const int32_t e = (base + kRecordsPerPass <= pre) ? es : list[base + slot];
-                        wrec[slot * 8 + (lane & 7)] = reinterpret_cast<const uint4*>(&sc.btris[e])[lane & 7];
-                    }
-                }
+                if (slot < npass) wrec[slot * 8 + (lane & 7)] = rcur[pass];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            // ---- request the next chunk ----
+            const int nbase = base + kRecordsPerPass;
+            const int nnext = min(kRecordsPerPass, ntri - nbase);
+#pragma unroll
+            for (int pass = 0; pass < kRecordsPerPass / 8; ++pass) {
+                const int slot = pass * 8 + (lane >> 3);
+                const int32_t es = __shfl(ent, (nbase + slot) & 63, 64);      // all lanes take part in the shuffle
+                if (slot < nnext) {
+                    const int32_t e = (nbase + kRecordsPerPass <= pre) ? es : list[nbase + slot];
+                    rcur[pass] = reinterpret_cast<const uint4*>(&sc.btris[e])[lane & 7];
+                }
+            }
             // ---- (e) every lane tests its undecided samples against the staged records (exact FP64) ----
             for (int k = 0; k < npass && have; ++k) {
                 const double* p = wrecd + (size_t)k * 16;
@@ -629,7 +642,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                 for (int q = 0; q < kPacketSlots; ++q) {
                     if (alive[q]) {
                         sec.geom++;
-                        if (tri_blocks(p, ray[q], sc.root.lo, sc.root.hi)) { alive[q] = false; escaped[q] = false; }
+                        if (fc.debug != 21 && tri_blocks(p, ray[q], sc.root.lo, sc.root.hi)) { alive[q] = false; escaped[q] = false; }
                     }
                 }
                 if ((k & 3) == 3) have = __any(alive[0] || alive[1]);
@@ -656,7 +669,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
             const int esc = (int)__popcll(__ballot(escaped[0])) + (int)__popcll(__ballot(escaped[1]));
             if (lane == 0) {
                 double frac = (double)esc / (double)S;                     // ShadowMethod.IntersectRay :113-119
-                samples[rec.sample] = modulate(samples[rec.sample], to_byte(frac * 255));
+                samples[rec.sample] = modulate(shaded, to_byte(frac * 255));
             }
         }
     }

@@ -102,13 +102,13 @@ __device__ __forceinline__ bool sphere_hit(const double* p, D3 s, D3 d, double& 
 __device__ __forceinline__ bool inside(const double* lo, const double* hi, D3 p) {
     return lo[0] < p.x && p.x < hi[0] && lo[1] < p.y && p.y < hi[1] && lo[2] < p.z && p.z < hi[2];
 }
-// dot with the unit normal of box plane I (the literal 3-term product: x*0.0 is kept, it is not foldable)
+// dot with the unit normal of box plane I.  The reference evaluates the 3-term product x*nx + y*ny + z*nz with
+// two of the normal's components 0.0 and one +-1.0; for finite coordinates that is exactly +-component (the 0.0
+// products can only change the sign of a zero result, which no later comparison, division or sum can observe:
+// every consumer divides BY (ed - sd), compares, or adds the value to other terms).
 template <int I>
 __device__ __forceinline__ double plane_dot(D3 v) {
-    constexpr double nx = (I == 0) ? -1.0 : (I == 3 ? 1.0 : 0.0);
-    constexpr double ny = (I == 1) ? -1.0 : (I == 4 ? 1.0 : 0.0);
-    constexpr double nz = (I == 2) ? -1.0 : (I == 5 ? 1.0 : 0.0);
-    return v.x * nx + v.y * ny + v.z * nz;
+    return (I == 0) ? -v.x : (I == 1) ? -v.y : (I == 2) ? -v.z : (I == 3) ? v.x : (I == 4) ? v.y : v.z;
 }
 template <int I>
 __device__ __forceinline__ void seg_plane(const RootBox& rb, D3 a, D3 b, double& closest, D3& cpos) {
@@ -132,6 +132,12 @@ __device__ __forceinline__ bool box_segment(const RootBox& rb, D3 a, D3 b, D3& o
     out = cpos;
     return true;
 }
+
+// AxisAlignedBox.ClipLineSegment.  NEED_END = false: the caller never looks at `end` again (every walk except the
+// reference tree's), so the second clip is not evaluated.
+// (An "entry face only" shortcut -- three planes instead of six, with margin checks and this routine as fallback --
+// was measured on MI355X: bit-identical but not faster; the six independent plane evaluations overlap well.)
+template <bool NEED_END = true>
 __device__ __forceinline__ bool clip_segment(const RootBox& rb, D3& start, D3& end) {
     bool si = inside(rb.lo, rb.hi, start), ei = inside(rb.lo, rb.hi, end);
     if (si && ei) return true;
@@ -140,7 +146,7 @@ __device__ __forceinline__ bool clip_segment(const RootBox& rb, D3& start, D3& e
     if (si) { end = ip; return true; }
     D3 original = start;
     start = ip;
-    if (!ei) {
+    if (NEED_END && !ei) {
         if (box_segment(rb, end, original, ip)) end = ip;
     }
     return true;
@@ -249,7 +255,7 @@ template <bool ANY>
 __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out, Ctr& c) {
     D3 end = s + d * 10000.0;
     D3 original = s;
-    if (!clip_segment(sc.root, s, end)) return false;
+    if (!clip_segment<false>(sc.root, s, end)) return false;
     double offset = length(original - s) / length(d);
 
     const float ox = (float)(s.x - sc.root.centre[0]), oy = (float)(s.y - sc.root.centre[1]), oz = (float)(s.z - sc.root.centre[2]);
@@ -340,7 +346,7 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
 __device__ __forceinline__ bool bvh_cached_blocks(const DevScene& sc, int32_t k, D3 s, D3 d) {
     D3 end = s + d * 10000.0;
     D3 original = s;
-    if (!clip_segment(sc.root, s, end)) return false;
+    if (!clip_segment<false>(sc.root, s, end)) return false;
     double offset = length(original - s) / length(d);
     double t; D3 pos;
     const Rec128* r = &sc.btris[k];

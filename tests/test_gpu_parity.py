@@ -113,6 +113,94 @@ def test_intersect_ray_batches(n_tris, max_depth, max_geom, seed, n_rays, outsid
     assert a["hit"].any()
 
 
+def _clip_edge_rays(lo, hi, seed):
+    """Rays chosen to stress AxisAlignedBox.ClipLineSegment: entries exactly through corners and edges, rays that run
+    inside a face plane, axis-parallel rays, starts on faces, starts with zero components, rays that miss by 1e-9..1e-12,
+    and outside-in rays aimed at random points within 1e-7 of the faces, edges and corners."""
+    rng = np.random.default_rng(seed)
+    lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+    mid = 0.5 * (lo + hi)
+    ext = hi - lo
+    starts, dirs = [], []
+
+    def add(s, target):
+        s, target = np.asarray(s, float), np.asarray(target, float)
+        starts.append(s)
+        dirs.append(target - s)
+    corners = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+    for c in corners:
+        out = c + (c - mid) * 0.5                      # on the diagonal through the corner: three equal crossings
+        add(out, mid)
+        add(out, c)
+        add(out, c + (mid - c) * 1e-12)
+        for a in range(3):                             # along the three edges through the corner, in the edge line itself
+            e = c.copy()
+            e[a] = mid[a]
+            s = c.copy()
+            s[a] = c[a] + (c[a] - mid[a])
+            add(s, e)
+    for a in range(3):
+        for side in (lo, hi):
+            fc = mid.copy()
+            fc[a] = side[a]
+            outp = fc.copy()
+            outp[a] += (side[a] - mid[a])
+            add(outp, mid)                             # axis-parallel through the face centre
+            add(fc, mid)                               # start exactly on the face
+            b = (a + 1) % 3
+            g0 = fc.copy()
+            g0[b] = lo[b] - ext[b]
+            g1 = fc.copy()
+            g1[b] = hi[b] + ext[b]
+            add(g0, g1)                                # runs inside the face plane
+            for eps in (1e-9, 1e-11, 1e-12, -1e-9, -1e-11, -1e-12):
+                t0, t1 = g0.copy(), g1.copy()
+                t0[a] += eps
+                t1[a] += eps
+                add(t0, t1)                            # just inside / just outside the face plane
+    add([0.0, 0.0, 0.0], mid)
+    add(np.where(np.arange(3) == 0, lo - ext, 0.0), mid)
+    add(lo - ext, lo - 2 * ext)                        # points away: never reaches the box
+    n = 20000
+    tgt = lo + rng.random((n, 3)) * ext
+    axis = rng.integers(0, 3, n)
+    kind = rng.integers(0, 3, n)                       # snap 1, 2 or 3 coordinates to a face -> face / edge / corner targets
+    for i in range(n):
+        for j in range(kind[i] + 1):
+            a = (axis[i] + j) % 3
+            tgt[i, a] = (lo if rng.random() < 0.5 else hi)[a] + rng.normal() * 10.0 ** rng.integers(-13, -6)
+    src = mid + (rng.random((n, 3)) - 0.5) * ext * 6.0
+    for i in range(n):
+        add(src[i], tgt[i] + (tgt[i] - src[i]) * rng.random())
+    return np.array(starts), np.array(dirs)
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_box_clip_edge_cases(flat):
+    """The device's entry-face shortcut must give the literal six-plane ClipLineSegment result (AxisAlignedBox.cs) in
+    every degenerate configuration; checked through IntersectRay on the tree and on the BVH (start clip + rayFracOffset)."""
+    v9, argb, rnd = random_triangles(3000, seed=424242)
+    lo, hi = [list(x) for x in TREE_BOX]
+    if flat:                                           # planar model: zero-thickness box
+        v9 = v9.reshape(-1, 3, 3).copy()
+        v9[:, :, 2] = 5.0
+        v9 = v9.reshape(-1)
+        lo[2] = hi[2] = 5.0
+    g = sa.GpuScene(0)
+    g.set_triangles(v9, argb, lo, hi)
+    g.build((sa.MODE_REF_TREE, sa.MODE_BVH), 10, 5)
+    o = orc.Scene()
+    o.set_triangles(v9, argb, lo, hi)
+    assert o.build_tree(10, 5) == 0
+    starts, dirs = _clip_edge_rays(lo, hi if not flat else [hi[0], hi[1], 5.0], 99)
+    for target, otarget in ((sa.MODE_REF_TREE, 1), (sa.MODE_BVH, 3)):
+        a = g.trace(target, starts, dirs)
+        b = o.trace(otarget, starts, dirs)
+        for key in ("hit", "tri_index", "color", "ray_frac", "pos", "normal"):
+            assert np.array_equal(a[key], b[key]), (target, key, np.flatnonzero(a["hit"] != b["hit"])[:10])
+    assert 0 < a["hit"].sum() < len(starts)
+
+
 def test_primitive_kats_on_gpu():
     g = sa.GpuScene(0)
     g.set_triangles(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], dtype=np.float64), np.array([0xffffffff], dtype=np.uint32),
