@@ -263,12 +263,13 @@ struct Aabb {
 struct ChildRef { int32_t c, n; Aabb box; };
 
 struct BvhBuilder {
-    static constexpr int kLeafMax = 4, kBins = 16;
+    static constexpr int kBins = 16;
     std::vector<Aabb> tb;            // per-triangle bounds
     std::vector<double> cen;         // per-triangle centroid [n][3]
     Bvh& out;
     const RootBox& root;
     double pad;
+    int kLeafMax = 4;                // triangles per leaf (SR_BVH_LEAF = 1..4 overrides: experiment hook)
 
     float down(double v) const { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; }
     float up(double v) const { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; }
@@ -348,6 +349,7 @@ void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out) {
     double ext = 0;
     for (int a = 0; a < 3; ++a) ext = std::max(ext, root.max[a] - root.min[a]);
     BvhBuilder bb{{}, {}, out, root, std::ldexp(ext > 0 ? ext : 1.0, -16)};
+    if (const char* e = std::getenv("SR_BVH_LEAF")) bb.kLeafMax = std::min(7, std::max(1, std::atoi(e)));
     bb.tb.resize(n);
     bb.cen.resize(n * 3);
     out.order.resize(n);

@@ -305,6 +305,7 @@ constexpr int kShaftCap = 48;            // triangles per candidate list in the 
 // later rounds only see the hits whose earlier candidates left samples undecided: longer lists, fewer hits
 constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 256};
 constexpr int kRecordsPerPass = 16;      // records staged through LDS per pass (2 KB per wave)
+constexpr int kTailSlots = 64;           // k_shadow_test switches to (sample x candidate) lanes once this few samples are undecided
 constexpr unsigned kTruncated = 0x80000000u;
 
 // The shaft is parametrised from the surface end: C(u) = E' + u (L - E'), u in [0, 1] (u = 1 - t), so that all fp32
@@ -312,24 +313,34 @@ constexpr unsigned kTruncated = 0x80000000u;
 // R u.  Can any point of the centre segment, u in [ua, ub], lie within rho of the triangle?  Necessary condition
 // (conservative): the segment meets the slab |n.x - d| <= rho and the three edge half-spaces m_k.x - c_k >= -rho.
 // Each constraint is linear in u, so it clips the interval.
-// one linear constraint f0 + u f1 >= bound, with the reciprocal of f1 precomputed (v_rcp_f32: 1 ulp, far inside the
-// 1e-6 slack of the final comparison)
-struct Lin {
-    float f0, inv;      // inv = 1/f1, or 0 when f1 == 0
-    int   sgn;          // sign of f1: +1, -1, 0
+// k_shaft is fp32 VALU-throughput bound (SQ_ACTIVE_INST_VALU ~ 90 % of the SIMD cycles), so its inner parts are
+// written for instruction count: packed fp32 FMAs (v_pk_fma_f32: two lanes of a register pair per issue slot),
+// select-free interval clipping, v_rcp_f32 instead of IEEE divisions.  All of it is conservative filtering (the exact
+// FP64 tests run in k_shadow_test), so fused / reordered roundings are covered by the pads.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
+
+struct ShaftRay {
+    f2    edx, edy, edz;        // per axis (E' , L - E'): value and slope of the centre ray C(u) = E' + u (L - E')
+    float R, pad, ext, hbx, hby, hbz;
 };
-__device__ __forceinline__ Lin make_lin(float f0, float f1) {
-    Lin l;
-    l.f0 = f0;
-    l.sgn = (f1 > 0.0f) ? 1 : ((f1 < 0.0f) ? -1 : 0);
-    l.inv = l.sgn ? __builtin_amdgcn_rcpf(f1) : 0.0f;
-    return l;
+
+// reciprocal slope of a linear function f0 + u f1; a (nearly) zero slope acts as a huge positive one: the function is
+// constant over u in [0, 1] to far below the pads, and the clip below then keeps everything when f0 satisfies the bound
+// and nothing otherwise.  The result is always finite, so the clips never see inf * 0.
+__device__ __forceinline__ float slope_inv(float f1) { return fabsf(f1) < 1e-30f ? 1e30f : __builtin_amdgcn_rcpf(f1); }
+// |f0 + u f1| <= rho
+__device__ __forceinline__ void clip_abs(float f0, float inv, float rho, float& ua, float& ub) {
+    const float v1 = (-rho - f0) * inv, v2 = (rho - f0) * inv;
+    ua = fmaxf(ua, fminf(v1, v2));
+    ub = fminf(ub, fmaxf(v1, v2));
 }
-__device__ __forceinline__ void clip_ge(const Lin& l, float bound, float& ua, float& ub) {
-    const float v = (bound - l.f0) * l.inv;
-    if (l.sgn > 0) ua = fmaxf(ua, v);
-    else if (l.sgn < 0) ub = fminf(ub, v);
-    else if (!(l.f0 >= bound)) ub = -1e30f;
+// f0 + u f1 >= -rho;  big = copysign(1e30, inv): the open end of the half line
+__device__ __forceinline__ void clip_ge(float f0, float inv, float big, float rho, float& ua, float& ub) {
+    const float v = (-rho - f0) * inv;
+    ua = fmaxf(ua, fminf(v, big));
+    ub = fminf(ub, fmaxf(v, big));
 }
 // returns 0: no sample ray can touch the triangle; 1: candidate; 2: UMBRA -- every possible sample ray crosses this
 // triangle well inside it, in front of the surface point: the hit point is fully shadowed whatever the samples are.
@@ -341,39 +352,43 @@ __device__ __forceinline__ void clip_ge(const Lin& l, float bound, float& ua, fl
 // min over [ulo, uhi] of (k0 + u k1) - R uhi.  If that exceeds the margin for the three edges, the crossing lies
 // strictly inside the triangle (hence inside the root box), at 0 < t < 1: Triangle.IntersectRay accepts it and
 // rayFrac <= 1.0 for every sample (ShadowMethod.cs:170), so rayEscapeCount = 0.
-__device__ __forceinline__ int shaft_touches(const TriSlab s, float ex, float ey, float ez, float dx, float dy, float dz,
-                                             float ua, float ub, float R, float pad, float ext, float hbx, float hby, float hbz) {
-    const float n0 = s.n[0] * ex + s.n[1] * ey + s.n[2] * ez - s.d, n1 = s.n[0] * dx + s.n[1] * dy + s.n[2] * dz;
-    const float p0 = s.m1[0] * ex + s.m1[1] * ey + s.m1[2] * ez - s.c1, p1 = s.m1[0] * dx + s.m1[1] * dy + s.m1[2] * dz;
-    const float q0 = s.m2[0] * ex + s.m2[1] * ey + s.m2[2] * ez - s.c2, q1 = s.m2[0] * dx + s.m2[1] * dy + s.m2[2] * dz;
-    const float r0 = s.m3[0] * ex + s.m3[1] * ey + s.m3[2] * ez - s.c3, r1 = s.m3[0] * dx + s.m3[1] * dy + s.m3[2] * dz;
-    const Lin ln = make_lin(n0, n1), lm = make_lin(-n0, -n1);
-    const Lin l1 = make_lin(p0, p1), l2 = make_lin(q0, q1), l3 = make_lin(r0, r1);
+__device__ __forceinline__ int shaft_touches(const TriSlab s, const ShaftRay& sr, float ua, float ub) {
+    // (f0, f1) of the plane and the three edge planes along the centre ray, two lanes per packed FMA
+    f2 cn = {-s.d, 0.0f}, c1 = {-s.c1, 0.0f}, c2 = {-s.c2, 0.0f}, c3 = {-s.c3, 0.0f};
+    const f2 N = pk_fma(splat(s.n[0]), sr.edx, pk_fma(splat(s.n[1]), sr.edy, pk_fma(splat(s.n[2]), sr.edz, cn)));
+    const f2 P = pk_fma(splat(s.m1[0]), sr.edx, pk_fma(splat(s.m1[1]), sr.edy, pk_fma(splat(s.m1[2]), sr.edz, c1)));
+    const f2 Q = pk_fma(splat(s.m2[0]), sr.edx, pk_fma(splat(s.m2[1]), sr.edy, pk_fma(splat(s.m2[2]), sr.edz, c2)));
+    const f2 T = pk_fma(splat(s.m3[0]), sr.edx, pk_fma(splat(s.m3[1]), sr.edy, pk_fma(splat(s.m3[2]), sr.edz, c3)));
+    const float in = slope_inv(N.y), ip = slope_inv(P.y), iq = slope_inv(Q.y), it3 = slope_inv(T.y);
+    const float bp = __builtin_copysignf(1e30f, ip), bq = __builtin_copysignf(1e30f, iq), bt = __builtin_copysignf(1e30f, it3);
     // the shaft radius at the far end of the current interval bounds the deviation; clipping shrinks the interval,
     // which shrinks the radius: one refinement
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
-        const float rho = R * fminf(1.0f, fmaxf(0.0f, ub + 1e-5f)) + pad;
-        clip_ge(ln, -rho, ua, ub);
-        clip_ge(lm, -rho, ua, ub);
-        clip_ge(l1, -rho, ua, ub);
-        clip_ge(l2, -rho, ua, ub);
-        clip_ge(l3, -rho, ua, ub);
+        const float rho = __builtin_fmaf(sr.R, fminf(1.0f, fmaxf(0.0f, ub + 1e-5f)), sr.pad);
+        clip_abs(N.x, in, rho, ua, ub);
+        clip_ge(P.x, ip, bp, rho, ua, ub);
+        clip_ge(Q.x, iq, bq, rho, ua, ub);
+        clip_ge(T.x, it3, bt, rho, ua, ub);
         if (!(ua <= ub + 1e-6f)) return 0;
     }
     // ---- umbra test ----
-    const float Rm = R * 1.001f;
+    const float Rm = sr.R * 1.001f;
+    const float n0 = N.x, n1 = N.y;
     if (n1 > 2.0f * Rm && n0 < 0.0f) {                          // front-facing for all samples, plane between light and surface point
-        const float ulo = -n0 / (n1 + Rm), uhi = -n0 / (n1 - Rm);
+        // v_rcp_f32 is good to 1 ulp; the factors move the bounds outwards by 2e-6
+        const float ulo = -n0 * __builtin_amdgcn_rcpf(n1 + Rm) * 0.999998f, uhi = -n0 * __builtin_amdgcn_rcpf(n1 - Rm) * 1.000002f;
         if (ulo > 2e-4f && uhi < 0.5f) {
-            const float margin = Rm * uhi + 3e-5f * ext;             // fp32 evaluation error of an edge function is < 2e-6 * extent
-            const float e1 = fminf(p0 + ulo * p1, p0 + uhi * p1), e2 = fminf(q0 + ulo * q1, q0 + uhi * q1), e3 = fminf(r0 + ulo * r1, r0 + uhi * r1);
+            const float margin = __builtin_fmaf(Rm, uhi, 3e-5f * sr.ext);      // fp32 evaluation error of an edge function is < 2e-6 * extent
+            const float e1 = fminf(__builtin_fmaf(ulo, P.y, P.x), __builtin_fmaf(uhi, P.y, P.x));
+            const float e2 = fminf(__builtin_fmaf(ulo, Q.y, Q.x), __builtin_fmaf(uhi, Q.y, Q.x));
+            const float e3 = fminf(__builtin_fmaf(ulo, T.y, T.x), __builtin_fmaf(uhi, T.y, T.x));
             if (e1 > margin && e2 > margin && e3 > margin) {
                 // the crossing region must also be inside the root box (hits outside it are no hits: SpatialSubdivision.cs:652)
-                const float ax = ex + ulo * dx, ay = ey + ulo * dy, az = ez + ulo * dz;
-                const float bx = ex + uhi * dx, by = ey + uhi * dy, bz = ez + uhi * dz;
-                const float m = margin;
-                if (fmaxf(fabsf(ax), fabsf(bx)) + m < hbx && fmaxf(fabsf(ay), fabsf(by)) + m < hby && fmaxf(fabsf(az), fabsf(bz)) + m < hbz) return 2;
+                const f2 U = {ulo, uhi};
+                const f2 X = pk_fma(U, splat(sr.edx.y), splat(sr.edx.x)), Y = pk_fma(U, splat(sr.edy.y), splat(sr.edy.x)), Z = pk_fma(U, splat(sr.edz.y), splat(sr.edz.x));
+                if (fmaxf(fabsf(X.x), fabsf(X.y)) + margin < sr.hbx && fmaxf(fabsf(Y.x), fabsf(Y.y)) + margin < sr.hby &&
+                    fmaxf(fabsf(Z.x), fabsf(Z.y)) + margin < sr.hbz) return 2;
             }
         }
     }
@@ -404,9 +419,18 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         const float pad_tri = ext * 7.62939453125e-6f;                     // 2^-17 * extent: fp32 plane evaluation + fp64 hit-test slack
         const float ex = (float)(E.x - sc.root.centre[0]), ey = (float)(E.y - sc.root.centre[1]), ez = (float)(E.z - sc.root.centre[2]);
         const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
-        const float ix = 1.0f / dx, iy = 1.0f / dy, iz = 1.0f / dz;
+        // a zero direction component acts as a huge finite slope reciprocal: no inf - inf in the fused slab arithmetic
+        const float ix = dx != 0.0f ? 1.0f / dx : 1e30f, iy = dy != 0.0f ? 1.0f / dy : 1e30f, iz = dz != 0.0f ? 1.0f / dz : 1e30f;
+        // slab test of a box inflated by r, per axis: t_lo = lo*i + (-o*i - r*i), t_hi = hi*i + (-o*i + r*i); the node's
+        // floats are consumed in memory order as pairs (lo.x, lo.y) (lo.z, hi.x) (hi.y, hi.z)
+        const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
+        const f2 OI01 = {-ex * ix, -ey * iy}, OI20 = {-ez * iz, -ex * ix}, OI12 = {-ey * iy, -ez * iz};
+        const f2 RI01 = {-ix, -iy}, RI20 = {-iz, ix}, RI12 = {iy, iz};
         const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
-        const float hbx = 0.5f * (float)(sc.root.max[0] - sc.root.min[0]), hby = 0.5f * (float)(sc.root.max[1] - sc.root.min[1]), hbz = 0.5f * (float)(sc.root.max[2] - sc.root.min[2]);
+        ShaftRay sr;
+        sr.edx = (f2){ex, dx}; sr.edy = (f2){ey, dy}; sr.edz = (f2){ez, dz};
+        sr.R = R; sr.pad = pad_tri; sr.ext = ext;
+        sr.hbx = 0.5f * (float)(sc.root.max[0] - sc.root.min[0]); sr.hby = 0.5f * (float)(sc.root.max[1] - sc.root.min[1]); sr.hbz = 0.5f * (float)(sc.root.max[2] - sc.root.min[2]);
         const int nbits = sc.bnode_bits, qmax = (1 << (31 - nbits)) - 1;   // stack word = node | quantised u bound
         const float qinv = 1.0f / (float)qmax * 1.000001f;
         int32_t* out = cand + (size_t)slot_i * cap;
@@ -422,15 +446,20 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
             while (ni >= 0 && leafA < 0) {
                 const BvhNode n = sc.bnodes[ni];
                 nodes++;
-                const float r = R * fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)) + pad;
-                float elo[3], ehi[3];
+                const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
+                const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
                 float a0, b0, a1, b1;      // child u-intervals [a, b]
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { elo[a] = n.lo0[a] - r; ehi[a] = n.hi0[a] + r; }
-                slab(elo, ehi, ex, ey, ez, ix, iy, iz, a0, b0);
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { elo[a] = n.lo1[a] - r; ehi[a] = n.hi1[a] + r; }
-                slab(elo, ehi, ex, ey, ez, ix, iy, iz, a1, b1);
+                {
+                    const f2 T0 = pk_fma((f2){n.lo0[0], n.lo0[1]}, I01, B0), T1 = pk_fma((f2){n.lo0[2], n.hi0[0]}, I20, B1), T2 = pk_fma((f2){n.hi0[1], n.hi0[2]}, I12, B2);
+                    // fminf/fmaxf drop a NaN operand: conservative
+                    a0 = fmaxf(fmaxf(fminf(T0.x, T1.y), fminf(T0.y, T2.x)), fminf(T1.x, T2.y));
+                    b0 = fminf(fminf(fmaxf(T0.x, T1.y), fmaxf(T0.y, T2.x)), fmaxf(T1.x, T2.y));
+                }
+                {
+                    const f2 T0 = pk_fma((f2){n.lo1[0], n.lo1[1]}, I01, B0), T1 = pk_fma((f2){n.lo1[2], n.hi1[0]}, I20, B1), T2 = pk_fma((f2){n.hi1[1], n.hi1[2]}, I12, B2);
+                    a1 = fmaxf(fmaxf(fminf(T0.x, T1.y), fminf(T0.y, T2.x)), fminf(T1.x, T2.y));
+                    b1 = fminf(fminf(fmaxf(T0.x, T1.y), fmaxf(T0.y, T2.x)), fmaxf(T1.x, T2.y));
+                }
                 a0 = fmaxf(a0, umin); a1 = fmaxf(a1, umin);
                 b0 = fminf(b0, nu); b1 = fminf(b1, nu);
                 const bool h0 = n.n0 >= 0 && a0 <= b0, h1 = n.n1 >= 0 && a1 <= b1;
@@ -467,7 +496,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                 leaves++;
                 slabs += (uint32_t)cnt;
                 for (int q = 0; q < cnt; ++q) {
-                    const int touch = shaft_touches(sc.bslab[first + q], ex, ey, ez, dx, dy, dz, ua, ub, R, pad_tri, ext, hbx, hby, hbz);
+                    const int touch = shaft_touches(sc.bslab[first + q], sr, ua, ub);
                     if (touch == 2) umbra = true;
                     if (touch) {
                         if (count < cap) { if (count >= 0) out[count] = first + q; count++; }
@@ -513,9 +542,10 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                                                      uint32_t* __restrict__ samples, unsigned long long* stats) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // per-wave LDS: kRecordsPerPass records of 128 B
-    uint4* wrec = reinterpret_cast<uint4*>(lds_pipe) + (size_t)wave * (kRecordsPerPass * 8);
+    // per-wave LDS: kRecordsPerPass records of 128 B, then kTailSlots compacted sample rays of 64 B
+    uint4* wrec = reinterpret_cast<uint4*>(lds_pipe) + (size_t)wave * (kRecordsPerPass * 8 + kTailSlots * 4);
     const double* wrecd = reinterpret_cast<const double*>(wrec);
+    double* wray = reinterpret_cast<double*>(wrec + kRecordsPerPass * 8);
 
     const int S = fc.shadow_samples;
     const unsigned int total = min(*hit_count, count_cap);
@@ -612,6 +642,10 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
         uint4 rcur[kRecordsPerPass / 8];
 #pragma unroll
         for (int pass = 0; pass < kRecordsPerPass / 8; ++pass) rcur[pass] = r0[pass];
+        bool tail = false;                         // wave-uniform
+        int tail_sh = 5;                           // log2 of the sample-slot count of a pass: 8, 16, 32 or 64
+        unsigned long long tail_alive = 0ull, tail_blocked = 0ull;   // per compacted sample slot, wave-uniform
+        int tail_idx[kPacketSlots] = {0, 0};       // this lane's samples' slots
         for (int base = 0; base < ntri && have; base += kRecordsPerPass) {
             const int npass = min(kRecordsPerPass, ntri - base);
             sec.nodes += (uint32_t)npass;
@@ -636,19 +670,112 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                 }
             }
             // ---- (e) every lane tests its undecided samples against the staged records (exact FP64) ----
-            for (int k = 0; k < npass && have; ++k) {
-                const double* p = wrecd + (size_t)k * 16;
+            int k = 0;
+            if (!tail) {
+                for (; k < npass && have; ++k) {
+                    const double* p = wrecd + (size_t)k * 16;
 #pragma unroll
-                for (int q = 0; q < kPacketSlots; ++q) {
-                    if (alive[q]) {
-                        sec.geom++;
-                        if (fc.debug != 21 && tri_blocks(p, ray[q], sc.root.lo, sc.root.hi)) { alive[q] = false; escaped[q] = false; }
+                    for (int q = 0; q < kPacketSlots; ++q) {
+                        if (alive[q]) {
+                            sec.geom++;
+                            if (fc.debug != 21 && tri_blocks(p, ray[q], sc.root.lo, sc.root.hi)) { alive[q] = false; escaped[q] = false; }
+                        }
+                    }
+                    if ((k & 3) == 3 || k == npass - 1) {
+                        const unsigned long long m0 = __ballot(alive[0]), m1 = __ballot(alive[1]);
+                        have = (m0 | m1) != 0ull;
+                        const int na = (int)__popcll(m0) + (int)__popcll(m1);
+                        if (have && na <= kTailSlots && fc.debug != 25) {
+                            // ---- few samples left: compact their rays into LDS; from here on a lane is one
+                            //      (sample, candidate) pair, so a pass tests 64 / tail_w candidates at once ----
+                            tail = true;
+                            tail_sh = na <= 8 ? 3 : (na <= 16 ? 4 : (na <= 32 ? 5 : 6));
+                            tail_alive = na >= 64 ? ~0ull : ((1ull << na) - 1ull);
+                            tail_blocked = 0ull;
+                            tail_idx[0] = (int)__popcll(m0 & lanemask_lt());
+                            tail_idx[1] = (int)__popcll(m0) + (int)__popcll(m1 & lanemask_lt());
+#pragma unroll
+                            for (int q = 0; q < kPacketSlots; ++q) {
+                                if (alive[q]) {
+                                    double* w = wray + (size_t)tail_idx[q] * 8;
+                                    w[0] = ray[q].s.x; w[1] = ray[q].s.y; w[2] = ray[q].s.z;
+                                    w[3] = ray[q].d.x; w[4] = ray[q].d.y; w[5] = ray[q].d.z;
+                                    w[6] = ray[q].offset;
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            ++k;
+                            break;
+                        }
                     }
                 }
-                if ((k & 3) == 3) have = __any(alive[0] || alive[1]);
+            }
+            if (tail) {
+                while (k < npass && tail_alive != 0ull) {
+                    const int tail_w = 1 << tail_sh, per = 64 >> tail_sh;    // sample slots, candidates per pass
+                    const int a = lane & (tail_w - 1), c = k + (lane >> tail_sh);
+                    const bool act = c < npass && ((tail_alive >> a) & 1ull) != 0ull;
+                    bool blk = false;
+                    if (act) {
+                        const double* w = wray + (size_t)a * 8;
+                        SampleRay r;
+                        r.s = mk(w[0], w[1], w[2]);
+                        r.d = mk(w[3], w[4], w[5]);
+                        r.offset = w[6];
+                        sec.geom++;
+                        blk = fc.debug != 21 && tri_blocks(wrecd + (size_t)c * 16, r, sc.root.lo, sc.root.hi);
+                    }
+                    unsigned long long m = __ballot(blk);
+                    // fold the per-pair results onto the sample slots (low tail_w bits)
+                    if (tail_sh <= 5) m |= m >> 32;
+                    if (tail_sh <= 4) m |= m >> 16;
+                    if (tail_sh <= 3) m |= m >> 8;
+                    const unsigned long long nb = m & tail_alive;
+                    tail_alive &= ~nb;
+                    tail_blocked |= nb;
+                    k += per;
+                    // ---- at most half of the slots still undecided: pack them again, twice the candidates per pass ----
+                    const int left = (int)__popcll(tail_alive);
+                    if (tail_sh > 3 && left > 0 && left <= (tail_w >> 1) && (k < npass || base + kRecordsPerPass < ntri)) {
+#pragma unroll
+                        for (int q = 0; q < kPacketSlots; ++q) {             // owners take the verdicts so far, then renumber
+                            if (alive[q]) {
+                                if (((tail_blocked >> tail_idx[q]) & 1ull) != 0ull) { alive[q] = false; escaped[q] = false; }
+                                else tail_idx[q] = (int)__popcll(tail_alive & ((1ull << tail_idx[q]) - 1ull));
+                            }
+                        }
+                        const bool mine = lane < tail_w && ((tail_alive >> lane) & 1ull) != 0ull;   // lane = old slot
+                        double t[7];
+                        if (mine) {
+#pragma unroll
+                            for (int i = 0; i < 7; ++i) t[i] = wray[(size_t)lane * 8 + i];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        if (mine) {
+                            double* w = wray + (size_t)__popcll(tail_alive & lanemask_lt()) * 8;
+#pragma unroll
+                            for (int i = 0; i < 7; ++i) w[i] = t[i];
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        tail_alive = (1ull << left) - 1ull;
+                        tail_blocked = 0ull;
+                        tail_sh = left <= 8 ? 3 : (left <= 16 ? 4 : 5);
+                    }
+                }
+                have = tail_alive != 0ull;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (tail) {
+            // hand the tail's verdicts back to the lanes that own the samples
+#pragma unroll
+            for (int q = 0; q < kPacketSlots; ++q) {
+                if (alive[q] && ((tail_blocked >> tail_idx[q]) & 1ull) != 0ull) { alive[q] = false; escaped[q] = false; }
             }
             have = __any(alive[0] || alive[1]);
-            __builtin_amdgcn_wave_barrier();
         }
         if (have && truncated) {
             // the list ran out before the shaft did and some sample is still undecided: next round (longer list),
@@ -838,7 +965,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         pipe_events(L, first ? K_SHADOW : K_SHADOW2, e0, e1);
         if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
         {
-            size_t lds = 4 * (size_t)kRecordsPerPass * 128;
+            size_t lds = 4 * ((size_t)kRecordsPerPass * 128 + (size_t)kTailSlots * 64);
             long long want = (max_items + 3) / 4;
             unsigned blocks = (unsigned)std::min<long long>(want, (long long)L.persistent_blocks * 2);
             const RoundState* st_in = first ? nullptr : (const RoundState*)L.round_state[round];
