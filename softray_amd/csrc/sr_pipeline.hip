@@ -301,7 +301,7 @@ __device__ __forceinline__ bool tri_blocks(const double* p, const SampleRay& r, 
 }
 
 constexpr int kPacketSlots = 2;          // samples per lane in k_shadow_test: S <= 128
-constexpr int kShaftCap = 48;            // triangles per candidate list in the first round (every hit)
+constexpr int kShaftCap = 64;            // triangles per candidate list in the first round (every hit)
 // later rounds only see the hits whose earlier candidates left samples undecided: longer lists, fewer hits
 constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 256};
 constexpr int kRecordsPerPass = 16;      // records staged through LDS per pass (2 KB per wave)
@@ -317,10 +317,6 @@ constexpr unsigned kTruncated = 0x80000000u;
 // written for instruction count: packed fp32 FMAs (v_pk_fma_f32: two lanes of a register pair per issue slot),
 // select-free interval clipping, v_rcp_f32 instead of IEEE divisions.  All of it is conservative filtering (the exact
 // FP64 tests run in k_shadow_test), so fused / reordered roundings are covered by the pads.
-typedef float f2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
-
 struct ShaftRay {
     f2    edx, edy, edz;        // per axis (E' , L - E'): value and slope of the centre ray C(u) = E' + u (L - E')
     float R, pad, ext, hbx, hby, hbz;
@@ -420,7 +416,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         const float ex = (float)(E.x - sc.root.centre[0]), ey = (float)(E.y - sc.root.centre[1]), ez = (float)(E.z - sc.root.centre[2]);
         const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
         // a zero direction component acts as a huge finite slope reciprocal: no inf - inf in the fused slab arithmetic
-        const float ix = dx != 0.0f ? 1.0f / dx : 1e30f, iy = dy != 0.0f ? 1.0f / dy : 1e30f, iz = dz != 0.0f ? 1.0f / dz : 1e30f;
+        const float ix = slab_inv(dx), iy = slab_inv(dy), iz = slab_inv(dz);
         // slab test of a box inflated by r, per axis: t_lo = lo*i + (-o*i - r*i), t_hi = hi*i + (-o*i + r*i); the node's
         // floats are consumed in memory order as pairs (lo.x, lo.y) (lo.z, hi.x) (hi.y, hi.z)
         const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
@@ -449,17 +445,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                 const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
                 const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
                 float a0, b0, a1, b1;      // child u-intervals [a, b]
-                {
-                    const f2 T0 = pk_fma((f2){n.lo0[0], n.lo0[1]}, I01, B0), T1 = pk_fma((f2){n.lo0[2], n.hi0[0]}, I20, B1), T2 = pk_fma((f2){n.hi0[1], n.hi0[2]}, I12, B2);
-                    // fminf/fmaxf drop a NaN operand: conservative
-                    a0 = fmaxf(fmaxf(fminf(T0.x, T1.y), fminf(T0.y, T2.x)), fminf(T1.x, T2.y));
-                    b0 = fminf(fminf(fmaxf(T0.x, T1.y), fmaxf(T0.y, T2.x)), fmaxf(T1.x, T2.y));
-                }
-                {
-                    const f2 T0 = pk_fma((f2){n.lo1[0], n.lo1[1]}, I01, B0), T1 = pk_fma((f2){n.lo1[2], n.hi1[0]}, I20, B1), T2 = pk_fma((f2){n.hi1[1], n.hi1[2]}, I12, B2);
-                    a1 = fmaxf(fmaxf(fminf(T0.x, T1.y), fminf(T0.y, T2.x)), fminf(T1.x, T2.y));
-                    b1 = fminf(fminf(fmaxf(T0.x, T1.y), fmaxf(T0.y, T2.x)), fmaxf(T1.x, T2.y));
-                }
+                node_slabs(n, I01, I20, I12, B0, B1, B2, a0, b0, a1, b1);
                 a0 = fmaxf(a0, umin); a1 = fmaxf(a1, umin);
                 b0 = fminf(b0, nu); b1 = fminf(b1, nu);
                 const bool h0 = n.n0 >= 0 && a0 <= b0, h1 = n.n1 >= 0 && a1 <= b1;

@@ -241,14 +241,30 @@ __device__ bool brute_intersect(const Rec128* tris, int ntris, D3 s, D3 d, Hit& 
 // Result = nearest hit (clipped start, hit inside the root box, ties -> lowest TriangleIndex); with ANY
 // it answers "is there a hit with rayFrac <= 1.0" (the only thing ShadowMethod.cs:170 asks).
 // --------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void slab(const float* lo, const float* hi, float ox, float oy, float oz,
-                                     float ix, float iy, float iz, float& tin, float& tout) {
-    float ax = (lo[0] - ox) * ix, bx = (hi[0] - ox) * ix;
-    float ay = (lo[1] - oy) * iy, by = (hi[1] - oy) * iy;
-    float az = (lo[2] - oz) * iz, bz = (hi[2] - oz) * iz;
-    // fminf/fmaxf drop a NaN operand ((lo-o)==0 times inf): conservative
-    tin = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
-    tout = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
+
+// Slab test of both children of a node as packed FMAs (v_pk_fma_f32: two floats per issue slot).  Per axis
+// t = plane * inv + bias with bias = -origin * inv (walks that inflate the boxes add -+r * inv); the node's twelve
+// floats are consumed in memory order as pairs (lo.x, lo.y) (lo.z, hi.x) (hi.y, hi.z), so I01 = (ix, iy),
+// I20 = (iz, ix), I12 = (iy, iz) and B0/B1/B2 are the matching bias pairs.  Rounding differs from (plane - origin) * inv
+// by at most a few ulp of |origin * inv|, far inside the 2^-16 * extent padding the boxes carry.  A zero direction
+// component must be given a huge FINITE reciprocal (slab_inv) so that no inf - inf appears.
+__device__ __forceinline__ float slab_inv(float d) { return d != 0.0f ? 1.0f / d : 1e30f; }
+__device__ __forceinline__ void node_slabs(const BvhNode& n, f2 I01, f2 I20, f2 I12, f2 B0, f2 B1, f2 B2,
+                                           float& a0, float& b0, float& a1, float& b1) {
+    {
+        const f2 T0 = pk_fma((f2){n.lo0[0], n.lo0[1]}, I01, B0), T1 = pk_fma((f2){n.lo0[2], n.hi0[0]}, I20, B1), T2 = pk_fma((f2){n.hi0[1], n.hi0[2]}, I12, B2);
+        // fminf/fmaxf drop a NaN operand: conservative
+        a0 = fmaxf(fmaxf(fminf(T0.x, T1.y), fminf(T0.y, T2.x)), fminf(T1.x, T2.y));
+        b0 = fminf(fminf(fmaxf(T0.x, T1.y), fmaxf(T0.y, T2.x)), fmaxf(T1.x, T2.y));
+    }
+    {
+        const f2 T0 = pk_fma((f2){n.lo1[0], n.lo1[1]}, I01, B0), T1 = pk_fma((f2){n.lo1[2], n.hi1[0]}, I20, B1), T2 = pk_fma((f2){n.hi1[1], n.hi1[2]}, I12, B2);
+        a1 = fmaxf(fmaxf(fminf(T0.x, T1.y), fminf(T0.y, T2.x)), fminf(T1.x, T2.y));
+        b1 = fminf(fminf(fmaxf(T0.x, T1.y), fmaxf(T0.y, T2.x)), fmaxf(T1.x, T2.y));
+    }
 }
 
 template <bool ANY>
@@ -259,7 +275,9 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
     double offset = length(original - s) / length(d);
 
     const float ox = (float)(s.x - sc.root.centre[0]), oy = (float)(s.y - sc.root.centre[1]), oz = (float)(s.z - sc.root.centre[2]);
-    const float ix = 1.0f / (float)d.x, iy = 1.0f / (float)d.y, iz = 1.0f / (float)d.z;
+    const float ix = slab_inv((float)d.x), iy = slab_inv((float)d.y), iz = slab_inv((float)d.z);
+    const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
+    const f2 B0 = {-ox * ix, -oy * iy}, B1 = {-oz * iz, -ox * ix}, B2 = {-oy * iy, -oz * iz};
     const float kInfl = 1.0f + 9.5367431640625e-7f;          // 1 + 2^-20
     float tlim = FLT_MAX;
     if (ANY) {
@@ -283,8 +301,7 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
             const BvhNode n = sc.bnodes[ni];
             c.nodes++;
             float t0, x0, t1, x1;
-            slab(n.lo0, n.hi0, ox, oy, oz, ix, iy, iz, t0, x0);
-            slab(n.lo1, n.hi1, ox, oy, oz, ix, iy, iz, t1, x1);
+            node_slabs(n, I01, I20, I12, B0, B1, B2, t0, x0, t1, x1);
             const bool h0 = n.n0 >= 0 && t0 <= x0 && x0 >= 0.0f && t0 <= tlim;
             const bool h1 = n.n1 >= 0 && t1 <= x1 && x1 >= 0.0f && t1 <= tlim;
             const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
