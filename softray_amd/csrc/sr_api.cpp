@@ -74,7 +74,7 @@ struct sr_scene {
     size_t      bvh_num_nodes = 0;
     // device state
     DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab;
-    DBuf d_offsets, d_rowmap, d_pixels, d_aa, d_stats, d_io[9], d_hits, d_samples, d_counters, d_fallback, d_rlist[sr::kShaftRounds], d_rstate[sr::kShaftRounds], d_rcount[sr::kShaftRounds], d_rcand[sr::kShaftRounds];
+    DBuf d_offsets, d_rowmap, d_pixels, d_aa, d_stats, d_io[9], d_hits, d_samples, d_counters, d_fallback, d_fallback_state, d_rlist[sr::kShaftRounds], d_rstate[sr::kShaftRounds], d_rcount[sr::kShaftRounds], d_rcand[sr::kShaftRounds];
     int num_cus = 0;
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
     std::vector<double>  offsets_host;
@@ -265,8 +265,9 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     const bool shadows = (fc.flags & SR_F_SHADOWS) != 0;
     const bool shaft = shadows && f->trace_mode == SR_MODE_BVH && (fc.flags & SR_F_POINT_LIGHT) && fc.shadow_samples <= 128 &&
                        !(f->flags & SR_F_PER_LANE_SHADOWS);
-    // samples per band: bounds the hit queue (64 B/sample) and, on the shaft path, the candidate lists (200 B/sample)
-    long long kMaxBandSamples = shaft ? (8ll << 20) : (32ll << 20);
+    // samples per band: bounds the hit queue (64 B/sample) and, on the shaft path, the candidate lists (256 B/sample for
+    // round 0 + 1/4 of the hits x 1 KB for round 1): 16 Mi samples = one 4096^2 frame = 10 GB of scratch in HBM
+    long long kMaxBandSamples = shaft ? (16ll << 20) : (32ll << 20);
     int round_cap[sr::kShaftRounds];
     for (int r = 0; r < sr::kShaftRounds; ++r) round_cap[r] = sr::pipeline_round_cap(r);
     {   // test hooks: shrink the bands / candidate lists so that small frames exercise banding, round 2 and the fallback
@@ -281,6 +282,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     unsigned round_items[sr::kShaftRounds] = {};
     if (shaft) {
         SR_HIP(s->d_fallback.reserve((size_t)band_samples * 4));
+        SR_HIP(s->d_fallback_state.reserve((size_t)band_samples * sr::pipeline_round_state_bytes()));
         for (int r = 0; r < sr::kShaftRounds; ++r) {
             // round 0 sees every hit; each later round is provisioned for 1/8 of the previous one
             round_items[r] = r == 0 ? (unsigned)band_samples : (unsigned)std::max<long long>(1024, (long long)round_items[r - 1] / 4);
@@ -308,6 +310,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     P.hits = s->d_hits.p;
     P.counters = (unsigned int*)s->d_counters.p;
     P.fallback = shaft ? (unsigned int*)s->d_fallback.p : nullptr;
+    P.fallback_state = shaft ? s->d_fallback_state.p : nullptr;
     for (int r = 0; r < sr::kShaftRounds; ++r) {
         P.round_items[r] = round_items[r];
         P.round_cap[r] = round_cap[r];
@@ -360,7 +363,7 @@ void sr_destroy(sr_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
-                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_fallback};
+                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_fallback, &s->d_fallback_state};
         for (DBuf* b : bufs) b->release();
         for (int r = 0; r < sr::kShaftRounds; ++r) { s->d_rlist[r].release(); s->d_rstate[r].release(); s->d_rcount[r].release(); s->d_rcand[r].release(); }
         for (DBuf& b : s->d_io) b.release();

@@ -64,6 +64,7 @@ struct PipelineLaunch {
     unsigned int* round_cand_count[kShaftRounds]; // device per-item candidate count | truncated flag
     int32_t*      round_cand[kShaftRounds];       // device [items][pipeline_round_cap(round)] (round_cand[0] == nullptr: no shaft path)
     unsigned int* fallback;     // device [band samples]: hits that need the exact per-lane fallback
+    void*         fallback_state; // device RoundState per fallback entry: which samples are still undecided
     int32_t     band_rows;      // rows per band (multiple of 16)
     int32_t     persistent_blocks;
     bool        per_lane_shadows; // force k_shadow (one lane per hit) instead of k_shadow_packet (cross-check)

@@ -42,8 +42,23 @@ __global__ __launch_bounds__(256, 5) void k_primary(DevScene sc, FrameConst fc, 
                                                  unsigned int* __restrict__ hit_count, unsigned long long* stats) {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
-    const int col = blockIdx.x * 16 + (wave & 1) * 8 + (lane & 7);
-    const int brow = blockIdx.y * 16 + (wave >> 1) * 8 + (lane >> 3);      // row inside this band
+    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup
+    // L runs on XCD L % 8; the 1-D grid is mapped so that every XCD walks through its own 8x8-tile super-tiles
+    // (128 x 128 pixels, neighbours share BVH nodes and triangle records in that XCD's L2), while at any time the eight
+    // XCDs work on different super-tile columns of the same super-tile row (skewed by the row: balanced load).
+    int tile_x, tile_y;
+    {
+        const int tiles_x = (fc.width + 15) >> 4, tiles_y = (row_count + 15) >> 4;
+        const int spx = (((tiles_x + 7) >> 3) + 7) >> 3;                 // super-tile columns per XCD
+        const int L = blockIdx.x, k = L & 7, j = L >> 3;
+        const int sj = j >> 6, t = j & 63;
+        const int sy = sj / spx, sx = (sj - sy * spx) * 8 + ((k + sy) & 7);
+        tile_x = sx * 8 + (t & 7);
+        tile_y = sy * 8 + (t >> 3);
+        if (tile_x >= tiles_x || tile_y >= tiles_y) return;              // padding of the super-tile grid (whole workgroup)
+    }
+    const int col = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
+    const int brow = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);          // row inside this band
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
     const bool live = col < fc.width && brow < row_count;
     const int crow = row_begin + brow;                                       // compact row of the frame
@@ -305,6 +320,11 @@ constexpr int kShaftCap = 64;            // triangles per candidate list in the 
 // later rounds only see the hits whose earlier candidates left samples undecided: longer lists, fewer hits
 constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 256};
 constexpr int kRecordsPerPass = 16;      // records staged through LDS per pass (2 KB per wave)
+// LDS strides (bank = address / 4 mod 64): in the (sample x candidate) layout the lanes of a wave read up to 8 different
+// records and up to 64 different rays at once; 144-byte records and 80-byte rays spread those over the banks
+// (128 / 64-byte strides would put them on 2 / 4 bank groups)
+constexpr int kRecStride16 = 9;          // record stride in 16-byte units (128 B payload)
+constexpr int kRayStride8 = 10;          // ray stride in doubles (7 used)
 constexpr int kTailSlots = 64;           // k_shadow_test switches to (sample x candidate) lanes once this few samples are undecided
 constexpr unsigned kTruncated = 0x80000000u;
 
@@ -525,13 +545,14 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                                                      unsigned int* __restrict__ next_count, unsigned int next_cap,
                                                      unsigned int* __restrict__ next_list, RoundState* __restrict__ state_out,
                                                      unsigned int* __restrict__ last_count, unsigned int* __restrict__ last_list,
+                                                     RoundState* __restrict__ last_state,
                                                      uint32_t* __restrict__ samples, unsigned long long* stats) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // per-wave LDS: kRecordsPerPass records of 128 B, then kTailSlots compacted sample rays of 64 B
-    uint4* wrec = reinterpret_cast<uint4*>(lds_pipe) + (size_t)wave * (kRecordsPerPass * 8 + kTailSlots * 4);
+    uint4* wrec = reinterpret_cast<uint4*>(lds_pipe) + (size_t)wave * (kRecordsPerPass * kRecStride16 + kTailSlots * kRayStride8 / 2);
     const double* wrecd = reinterpret_cast<const double*>(wrec);
-    double* wray = reinterpret_cast<double*>(wrec + kRecordsPerPass * 8);
+    double* wray = reinterpret_cast<double*>(wrec + kRecordsPerPass * kRecStride16);
 
     const int S = fc.shadow_samples;
     const unsigned int total = min(*hit_count, count_cap);
@@ -639,7 +660,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
 #pragma unroll
             for (int pass = 0; pass < kRecordsPerPass / 8; ++pass) {
                 const int slot = pass * 8 + (lane >> 3);
-                if (slot < npass) wrec[slot * 8 + (lane & 7)] = rcur[pass];
+                if (slot < npass) wrec[slot * kRecStride16 + (lane & 7)] = rcur[pass];
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -659,7 +680,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
             int k = 0;
             if (!tail) {
                 for (; k < npass && have; ++k) {
-                    const double* p = wrecd + (size_t)k * 16;
+                    const double* p = wrecd + (size_t)k * (2 * kRecStride16);
 #pragma unroll
                     for (int q = 0; q < kPacketSlots; ++q) {
                         if (alive[q]) {
@@ -683,7 +704,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
 #pragma unroll
                             for (int q = 0; q < kPacketSlots; ++q) {
                                 if (alive[q]) {
-                                    double* w = wray + (size_t)tail_idx[q] * 8;
+                                    double* w = wray + (size_t)tail_idx[q] * kRayStride8;
                                     w[0] = ray[q].s.x; w[1] = ray[q].s.y; w[2] = ray[q].s.z;
                                     w[3] = ray[q].d.x; w[4] = ray[q].d.y; w[5] = ray[q].d.z;
                                     w[6] = ray[q].offset;
@@ -704,13 +725,13 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                     const bool act = c < npass && ((tail_alive >> a) & 1ull) != 0ull;
                     bool blk = false;
                     if (act) {
-                        const double* w = wray + (size_t)a * 8;
+                        const double* w = wray + (size_t)a * kRayStride8;
                         SampleRay r;
                         r.s = mk(w[0], w[1], w[2]);
                         r.d = mk(w[3], w[4], w[5]);
                         r.offset = w[6];
                         sec.geom++;
-                        blk = fc.debug != 21 && tri_blocks(wrecd + (size_t)c * 16, r, sc.root.lo, sc.root.hi);
+                        blk = fc.debug != 21 && tri_blocks(wrecd + (size_t)c * (2 * kRecStride16), r, sc.root.lo, sc.root.hi);
                     }
                     unsigned long long m = __ballot(blk);
                     // fold the per-pair results onto the sample slots (low tail_w bits)
@@ -735,12 +756,12 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                         double t[7];
                         if (mine) {
 #pragma unroll
-                            for (int i = 0; i < 7; ++i) t[i] = wray[(size_t)lane * 8 + i];
+                            for (int i = 0; i < 7; ++i) t[i] = wray[(size_t)lane * kRayStride8 + i];
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         if (mine) {
-                            double* w = wray + (size_t)__popcll(tail_alive & lanemask_lt()) * 8;
+                            double* w = wray + (size_t)__popcll(tail_alive & lanemask_lt()) * kRayStride8;
 #pragma unroll
                             for (int i = 0; i < 7; ++i) w[i] = t[i];
                         }
@@ -769,13 +790,15 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
             const unsigned long long a0 = __ballot(alive[0]), a1 = __ballot(alive[1]), e0 = __ballot(escaped[0]), e1 = __ballot(escaped[1]);
             if (lane == 0) {
                 unsigned int slot = next_count ? atomicAdd(next_count, 1u) : 0xffffffffu;
+                RoundState o;
+                o.alive[0] = a0; o.alive[1] = a1; o.escaped[0] = e0; o.escaped[1] = e1;
                 if (slot < next_cap) {
                     next_list[slot] = h;
-                    RoundState o;
-                    o.alive[0] = a0; o.alive[1] = a1; o.escaped[0] = e0; o.escaped[1] = e1;
                     state_out[slot] = o;
                 } else {
-                    last_list[atomicAdd(last_count, 1u)] = h;
+                    const unsigned int fi = atomicAdd(last_count, 1u);    // the fallback only traces the undecided samples
+                    last_list[fi] = h;
+                    last_state[fi] = o;
                 }
             }
         } else {
@@ -804,8 +827,8 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
 template <bool EXTRA, bool STATS>
 __global__ __launch_bounds__(256) void k_shadow_wave(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
                                                      const HitRec* __restrict__ hits, const unsigned int* __restrict__ count,
-                                                     const unsigned int* __restrict__ index_list, uint32_t* __restrict__ samples,
-                                                     unsigned long long* stats) {
+                                                     const unsigned int* __restrict__ index_list, const RoundState* __restrict__ state,
+                                                     uint32_t* __restrict__ samples, unsigned long long* stats) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
@@ -817,14 +840,18 @@ __global__ __launch_bounds__(256) void k_shadow_wave(DevScene sc, FrameConst fc,
     for (unsigned int i = blockIdx.x * 4u + (unsigned)wave; i < total; i += nwaves) {
         const HitRec rec = hits[index_list[i]];
         const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
+        const RoundState stt = state[i];           // verdicts of the list rounds: only undecided samples are traced
         int esc = 0;
-        for (int j = lane; j < S; j += 64) {
-            D3 rs = lpos + mk(offsets[3 * j], offsets[3 * j + 1], offsets[3 * j + 2]);
-            D3 rd = E - rs;
-            Hit h;
-            sec.rays++;
-            bool blocked = root_intersect<MODE_BVH, true, EXTRA>(sc, sc.tris, sc.extra, st, rs, rd, h, sec) && !(h.t > 1.0);
-            if (!blocked) esc++;
+        for (int j = lane, q = 0; j < S; j += 64, ++q) {
+            bool escaped = ((stt.escaped[q] >> lane) & 1ull) != 0ull;
+            if (((stt.alive[q] >> lane) & 1ull) != 0ull) {
+                D3 rs = lpos + mk(offsets[3 * j], offsets[3 * j + 1], offsets[3 * j + 2]);
+                D3 rd = E - rs;
+                Hit h;
+                sec.rays++;
+                escaped = !(root_intersect<MODE_BVH, true, EXTRA>(sc, sc.tris, sc.extra, st, rs, rd, h, sec) && !(h.t > 1.0));
+            }
+            if (escaped) esc++;
         }
         esc = (int)wave_sum((uint32_t)esc);
         if (lane == 0) {
@@ -875,7 +902,10 @@ static int pipe_stack_levels(const DevScene& sc, int mode) {
 
 template <int MODE, bool EXTRA>
 static hipError_t launch_primary_t(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples) {
-    dim3 grid((L.fc.width + 15) / 16, (row_count + 15) / 16);
+    // 1-D grid over the padded super-tile grid (see the tile order in k_primary)
+    const int tiles_x = (L.fc.width + 15) / 16, tiles_y = (row_count + 15) / 16;
+    const int spx = (((tiles_x + 7) / 8) + 7) / 8, sny = (tiles_y + 7) / 8;
+    dim3 grid((unsigned)(spx * 8 * sny * 64));
     size_t lds = (size_t)pipe_stack_levels(L.sc, MODE) * 256 * 4;
     if (L.stats)
         hipLaunchKernelGGL((k_primary<MODE, EXTRA, true>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
@@ -951,7 +981,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         pipe_events(L, first ? K_SHADOW : K_SHADOW2, e0, e1);
         if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
         {
-            size_t lds = 4 * ((size_t)kRecordsPerPass * 128 + (size_t)kTailSlots * 64);
+            size_t lds = 4 * ((size_t)kRecordsPerPass * kRecStride16 * 16 + (size_t)kTailSlots * kRayStride8 * 8);
             long long want = (max_items + 3) / 4;
             unsigned blocks = (unsigned)std::min<long long>(want, (long long)L.persistent_blocks * 2);
             const RoundState* st_in = first ? nullptr : (const RoundState*)L.round_state[round];
@@ -962,8 +992,8 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
             // round 0 iterates the compacted list of hits that k_shaft could not decide by itself
             const unsigned int* t_count = first ? work0 : count_ptr;
             const unsigned int* t_list = first ? L.round_list[0] : ilist;
-            if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, samples, L.stats);
-            else hipLaunchKernelGGL((k_shadow_test<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, samples, L.stats);
+            if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
+            else hipLaunchKernelGGL((k_shadow_test<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
@@ -975,8 +1005,8 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
     {
         size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
         unsigned blocks = (unsigned)std::min<long long>((max_hits + 3) / 4, (long long)L.persistent_blocks * 2);
-        if (L.stats) hipLaunchKernelGGL((k_shadow_wave<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, fb_count, L.fallback, samples, L.stats);
-        else hipLaunchKernelGGL((k_shadow_wave<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, fb_count, L.fallback, samples, L.stats);
+        if (L.stats) hipLaunchKernelGGL((k_shadow_wave<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, fb_count, L.fallback, (const RoundState*)L.fallback_state, samples, L.stats);
+        else hipLaunchKernelGGL((k_shadow_wave<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, fb_count, L.fallback, (const RoundState*)L.fallback_state, samples, L.stats);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;

@@ -288,7 +288,6 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
     }
     double best = DBL_MAX;
     int32_t bestIdx = 0x7fffffff, bestK = -1;
-    D3 bestPos = mk(0, 0, 0);
 
     // "while-while" traversal: a lane first walks inner nodes until it owns a pending leaf (or is finished), and only
     // then the (long, FP64) triangle tests run -- so a wavefront executes the leaf code with most lanes busy instead of
@@ -336,7 +335,7 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
                     } else {
                         const int32_t idx = r->aux;
                         if (t < best || (t == best && idx < bestIdx)) {
-                            best = t; bestIdx = idx; bestK = k; bestPos = pos;
+                            best = t; bestIdx = idx; bestK = k;
                             tlim = (float)best * kInfl + 1e-30f;
                         }
                     }
@@ -347,7 +346,7 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
     if (ANY || bestK < 0) return false;
     const Rec128* r = &sc.btris[bestK];
     out.t = best + offset;
-    out.pos = bestPos;
+    out.pos = s + d * best;          // the expression plane_hit evaluated for the winning triangle (pos = start + dir * rayFrac)
     out.nrm = mk(r->p[0], r->p[1], r->p[2]);
     out.color = r->color;
     out.tri = r->aux;
