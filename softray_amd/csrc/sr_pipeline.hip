@@ -36,8 +36,9 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 // --------------------------------------------------------------------------------------------------
 // k_primary
 // --------------------------------------------------------------------------------------------------
-template <int MODE, bool EXTRA, bool STATS>
-__global__ __launch_bounds__(256, 5) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
+// SUB = false: one ray per pixel (rayTraceSubPixelRes == 1), compiled without the sub-pixel / focal-blur state
+template <int MODE, bool EXTRA, bool STATS, bool SUB>
+__global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
                                                  int row_count, uint32_t* __restrict__ samples, HitRec* __restrict__ hits,
                                                  unsigned int* __restrict__ hit_count, unsigned long long* stats) {
     const int tid = threadIdx.x;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256, 5) void k_primary(DevScene sc, FrameConst fc, 
     const bool live = col < fc.width && brow < row_count;
     const int crow = row_begin + brow;                                       // compact row of the frame
     const int row = live ? row_map[crow] : 0;
-    const int n = fc.sub_pixel_res, n2 = n * n;
+    const int n = SUB ? fc.sub_pixel_res : 1, n2 = n * n;
     const bool shadows = (fc.flags & 2u) != 0;
     const int width = fc.width, height = fc.height;
     // sample buffer: n == 1 -> the frame itself (final pixel position); n > 1 -> band-local [brow][col][n2]
@@ -900,18 +901,18 @@ static int pipe_stack_levels(const DevScene& sc, int mode) {
     return 1;
 }
 
-template <int MODE, bool EXTRA>
-static hipError_t launch_primary_t(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples) {
+template <int MODE, bool EXTRA, bool SUB>
+static hipError_t launch_primary_s(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples) {
     // 1-D grid over the padded super-tile grid (see the tile order in k_primary)
     const int tiles_x = (L.fc.width + 15) / 16, tiles_y = (row_count + 15) / 16;
     const int spx = (((tiles_x + 7) / 8) + 7) / 8, sny = (tiles_y + 7) / 8;
     dim3 grid((unsigned)(spx * 8 * sny * 64));
     size_t lds = (size_t)pipe_stack_levels(L.sc, MODE) * 256 * 4;
     if (L.stats)
-        hipLaunchKernelGGL((k_primary<MODE, EXTRA, true>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
+        hipLaunchKernelGGL((k_primary<MODE, EXTRA, true, SUB>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
                            samples, (HitRec*)L.hits, L.counters, L.stats);
     else
-        hipLaunchKernelGGL((k_primary<MODE, EXTRA, false>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
+        hipLaunchKernelGGL((k_primary<MODE, EXTRA, false, SUB>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
                            samples, (HitRec*)L.hits, L.counters, L.stats);
     return hipGetLastError();
 }
@@ -1029,7 +1030,8 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (L.get_events) L.get_events(L.user, K_PRIMARY, &e0, &e1);
         if (e0) { e = hipEventRecord(e0, L.stream); if (e != hipSuccess) return e; }
-        e = launch_primary_t<MODE, EXTRA>(L, row_begin, row_count, samples);
+        e = L.fc.sub_pixel_res > 1 ? launch_primary_s<MODE, EXTRA, true>(L, row_begin, row_count, samples)
+                                   : launch_primary_s<MODE, EXTRA, false>(L, row_begin, row_count, samples);
         if (e != hipSuccess) return e;
         if (e1) { e = hipEventRecord(e1, L.stream); if (e != hipSuccess) return e; }
         if (shadows) {
