@@ -640,11 +640,10 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                 bool blocked = false;
                 if (EXTRA) blocked = extras_block<EXTRA>(sc, rs, rd, sec);
                 if (blocked) escaped[k] = false;
-                else if (work && fc.debug != 22 && fc.debug != 23) alive[k] = prepare_sample(sc, rs, rd, ray[k]);   // outside the root box: nothing can block it
+                else if (work) alive[k] = prepare_sample(sc, rs, rd, ray[k]);   // outside the root box: nothing can block it
             }
         }
         bool have = __any(alive[0] || alive[1]);
-        if (fc.debug == 24) have = false;                  // timing experiment: clip only
         // rcur: the chunk about to be staged (the first one was requested before the clip); while a chunk is being
         // tested, the next chunk's records are already on their way (requested right after the LDS write)
         uint4 rcur[kRecordsPerPass / 8];
@@ -686,14 +685,14 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                     for (int q = 0; q < kPacketSlots; ++q) {
                         if (alive[q]) {
                             sec.geom++;
-                            if (fc.debug != 21 && tri_blocks(p, ray[q], sc.root.lo, sc.root.hi)) { alive[q] = false; escaped[q] = false; }
+                            if (tri_blocks(p, ray[q], sc.root.lo, sc.root.hi)) { alive[q] = false; escaped[q] = false; }
                         }
                     }
                     if ((k & 3) == 3 || k == npass - 1) {
                         const unsigned long long m0 = __ballot(alive[0]), m1 = __ballot(alive[1]);
                         have = (m0 | m1) != 0ull;
                         const int na = (int)__popcll(m0) + (int)__popcll(m1);
-                        if (have && na <= kTailSlots && fc.debug != 25) {
+                        if (have && na <= kTailSlots) {
                             // ---- few samples left: compact their rays into LDS; from here on a lane is one
                             //      (sample, candidate) pair, so a pass tests 64 / tail_w candidates at once ----
                             tail = true;
@@ -732,7 +731,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                         r.d = mk(w[3], w[4], w[5]);
                         r.offset = w[6];
                         sec.geom++;
-                        blk = fc.debug != 21 && tri_blocks(wrecd + (size_t)c * (2 * kRecStride16), r, sc.root.lo, sc.root.hi);
+                        blk = tri_blocks(wrecd + (size_t)c * (2 * kRecStride16), r, sc.root.lo, sc.root.hi);
                     }
                     unsigned long long m = __ballot(blk);
                     // fold the per-pair results onto the sample slots (low tail_w bits)
