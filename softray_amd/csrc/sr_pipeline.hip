@@ -518,6 +518,11 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
             samples[rec.sample] = modulate(samples[rec.sample], 0u);
             cand_count[slot_i] = 0u;
             if (fc.debug == 7) atomicAdd(dbg + 7, 1u);
+        } else if (work_list && count == 0 && !truncated && sc.nextra == 0) {
+            // first round, nothing in the whole shaft and no extra geometry: every sample escapes,
+            // rayEscapeCount = S -> (byte)(1.0 * 255) = 255 (ShadowMethod.cs:113-119); the pixel is finished here
+            samples[rec.sample] = modulate(samples[rec.sample], to_byte((double)fc.shadow_samples / (double)fc.shadow_samples * 255));
+            cand_count[slot_i] = 0u;
         } else {
             cand_count[slot_i] = (unsigned)max(count, 0) | (truncated ? kTruncated : 0u);
             if (work_list) work_list[atomicAdd(work_count, 1u)] = h;      // the compiler aggregates this per wavefront

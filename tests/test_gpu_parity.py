@@ -294,7 +294,7 @@ def test_shadow_sample_variants(obj_pair):
     offset table (what the C# shim passes), and > 128 samples (per-lane kernel instead of the shaft path)."""
     g, o = obj_pair
     rnd = orc.Random(4242)
-    for count in (1, 7, 64, 100, 130):
+    for count in (1, 7, 64, 65, 100, 128, 130):
         f = make_frame(72, 56, shadows=True, shadow_samples=count)
         if count == 1:
             table = np.zeros((1, 3))
