@@ -693,7 +693,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
                             if (tri_blocks(p, ray[q], sc.root.lo, sc.root.hi)) { alive[q] = false; escaped[q] = false; }
                         }
                     }
-                    if ((k & 3) == 3 || k == npass - 1) {
+                    {
                         const unsigned long long m0 = __ballot(alive[0]), m1 = __ballot(alive[1]);
                         have = (m0 | m1) != 0ull;
                         const int na = (int)__popcll(m0) + (int)__popcll(m1);
