@@ -74,7 +74,7 @@ struct sr_scene {
     size_t      bvh_num_nodes = 0;
     // device state
     DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab;
-    DBuf d_offsets, d_rowmap, d_pixels, d_aa, d_stats, d_io[9], d_hits, d_samples, d_counters, d_fallback, d_fallback_state, d_rlist[sr::kShaftRounds], d_rstate[sr::kShaftRounds], d_rcount[sr::kShaftRounds], d_rcand[sr::kShaftRounds];
+    DBuf d_offsets, d_rowmap, d_pixels, d_aa, d_stats, d_io[9], d_hits, d_samples, d_counters, d_fallback, d_fallback_state, d_fallback_rays, d_fallback_ovf, d_rlist[sr::kShaftRounds], d_rstate[sr::kShaftRounds], d_rcount[sr::kShaftRounds], d_rcand[sr::kShaftRounds];
     int num_cus = 0;
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
     std::vector<double>  offsets_host;
@@ -279,10 +279,17 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     band_rows = std::min<long long>(band_rows, ((long long)fc.num_rows + 15) / 16 * 16);
     const long long band_samples = band_rows * fc.width * n2;
     if (shadows) SR_HIP(s->d_hits.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
+    // fallback ray list: one 32-bit id (entry << 7 | sample; bands have < 2^25 entries) per undecided sample.  6 per band
+    // sample = 0.4 GB for a 4096^2 band; whatever it has no room for is taken by the one-wave-per-hit kernel.  Test hook
+    // SR_FB_RAY_CAP shrinks it
+    long long fallback_ray_cap = std::min<long long>(6 * band_samples, 0xfffffff0ll);
+    if (const char* e = std::getenv("SR_FB_RAY_CAP")) fallback_ray_cap = std::max(1ll, std::atoll(e));
     unsigned round_items[sr::kShaftRounds] = {};
     if (shaft) {
         SR_HIP(s->d_fallback.reserve((size_t)band_samples * 4));
         SR_HIP(s->d_fallback_state.reserve((size_t)band_samples * sr::pipeline_round_state_bytes()));
+        SR_HIP(s->d_fallback_rays.reserve((size_t)fallback_ray_cap * 4));
+        SR_HIP(s->d_fallback_ovf.reserve((size_t)band_samples * 4));
         for (int r = 0; r < sr::kShaftRounds; ++r) {
             // round 0 sees every hit; each later round is provisioned for 1/8 of the previous one
             round_items[r] = r == 0 ? (unsigned)band_samples : (unsigned)std::max<long long>(1024, (long long)round_items[r - 1] / 4);
@@ -311,6 +318,9 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     P.counters = (unsigned int*)s->d_counters.p;
     P.fallback = shaft ? (unsigned int*)s->d_fallback.p : nullptr;
     P.fallback_state = shaft ? s->d_fallback_state.p : nullptr;
+    P.fallback_rays = shaft ? (unsigned int*)s->d_fallback_rays.p : nullptr;
+    P.fallback_ray_cap = (unsigned int)fallback_ray_cap;
+    P.fallback_overflow = shaft ? (unsigned int*)s->d_fallback_ovf.p : nullptr;
     for (int r = 0; r < sr::kShaftRounds; ++r) {
         P.round_items[r] = round_items[r];
         P.round_cap[r] = round_cap[r];
@@ -363,7 +373,7 @@ void sr_destroy(sr_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
-                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_fallback, &s->d_fallback_state};
+                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_fallback, &s->d_fallback_state, &s->d_fallback_rays, &s->d_fallback_ovf};
         for (DBuf* b : bufs) b->release();
         for (int r = 0; r < sr::kShaftRounds; ++r) { s->d_rlist[r].release(); s->d_rstate[r].release(); s->d_rcount[r].release(); s->d_rcand[r].release(); }
         for (DBuf& b : s->d_io) b.release();

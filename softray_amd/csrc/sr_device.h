@@ -65,6 +65,9 @@ struct PipelineLaunch {
     int32_t*      round_cand[kShaftRounds];       // device [items][pipeline_round_cap(round)] (round_cand[0] == nullptr: no shaft path)
     unsigned int* fallback;     // device [band samples]: hits that need the exact per-lane fallback
     void*         fallback_state; // device RoundState per fallback entry: which samples are still undecided
+    unsigned int* fallback_rays;  // device [fallback_ray_cap]: (entry << 7 | sample) of every undecided sample
+    unsigned int  fallback_ray_cap;
+    unsigned int* fallback_overflow; // device [band samples]: entries the ray list had no room for
     int32_t     band_rows;      // rows per band (multiple of 16)
     int32_t     persistent_blocks;
     bool        per_lane_shadows; // force k_shadow (one lane per hit) instead of k_shadow_packet (cross-check)

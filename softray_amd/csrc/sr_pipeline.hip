@@ -319,7 +319,7 @@ __device__ __forceinline__ bool tri_blocks(const double* p, const SampleRay& r, 
 constexpr int kPacketSlots = 2;          // samples per lane in k_shadow_test: S <= 128
 constexpr int kShaftCap = 64;            // triangles per candidate list in the first round (every hit)
 // later rounds only see the hits whose earlier candidates left samples undecided: longer lists, fewer hits
-constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 256};
+constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 64};
 constexpr int kRecordsPerPass = 16;      // records staged through LDS per pass (2 KB per wave)
 // LDS strides (bank = address / 4 mod 64): in the (sample x candidate) layout the lanes of a wave read up to 8 different
 // records and up to 64 different rays at once; 144-byte records and 80-byte rays spread those over the banks
@@ -825,25 +825,120 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
 }
 
 // --------------------------------------------------------------------------------------------------
-// k_shadow_wave: exact fallback of the shaft path.  wave = hit point, lanes = area-light samples, every lane runs
-// full any-hit BVH traversals for its 1-2 samples (the lanes' rays converge on one point, so the walks are coherent).
-// Only the few hit points whose candidate lists overflowed in every round get here.
+// Exact fallback of the shaft path: hit points whose candidate lists overflowed in every round still have undecided
+// samples (masks in RoundState).  Each undecided sample is one any-hit BVH walk.
+//   k_fb_expand    lane = fallback entry: appends one ray id (entry << 7 | sample) per undecided sample to a ray list
+//                  (wave-level prefix sum, one atomicAdd per wave).  Entries that do not fit are flagged and listed
+//                  for k_shadow_wave.
+//   k_shadow_rays  lane = ray id: 64 rays of one to six hit points per wave instead of one hit point per wave with
+//                  most lanes idle (a hit point reaches the fallback with ~15 % of its samples undecided).  A blocked
+//                  sample clears its bit in the entry's escaped mask (atomicAnd).
+//   k_fb_resolve   lane = entry: rayEscapeCount = popcount of the escaped masks -> pixel.
+//   k_shadow_wave  wave = hit point, lanes = samples: the entries the ray list had no room for.
 // --------------------------------------------------------------------------------------------------
+constexpr unsigned int kFbOverflowFlag = 0x80000000u;     // in the fallback list: entry handled by k_shadow_wave
+
+__global__ __launch_bounds__(256) void k_fb_expand(const unsigned int* __restrict__ count, unsigned int* __restrict__ fb_list,
+                                                   const RoundState* __restrict__ state, unsigned int* __restrict__ rays,
+                                                   unsigned int ray_cap, unsigned int* __restrict__ ray_count,
+                                                   unsigned int* __restrict__ ovf_list, unsigned int* __restrict__ ovf_count) {
+    const int lane = threadIdx.x & 63;
+    const unsigned int total = *count;
+    const unsigned int stride = gridDim.x * 256u;
+    for (unsigned int i0 = blockIdx.x * 256u; i0 < total; i0 += stride) {      // whole waves stay in the loop
+        const unsigned int i = i0 + threadIdx.x;
+        unsigned long long a0 = 0ull, a1 = 0ull;
+        if (i < total) { a0 = state[i].alive[0]; a1 = state[i].alive[1]; }
+        const unsigned int n = (unsigned int)__popcll(a0) + (unsigned int)__popcll(a1);
+        unsigned int incl = n;                                                 // inclusive prefix sum over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const unsigned int v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        const unsigned int wave_total = __shfl(incl, 63, 64);
+        unsigned int base = 0;
+        if (lane == 63 && wave_total) base = atomicAdd(ray_count, wave_total);
+        base = __shfl(base, 63, 64) + incl - n;
+        if (n == 0) continue;
+        if (base + n > ray_cap || base + n < base) {                           // no room: the per-wave kernel takes this entry
+            for (unsigned int k = base; k < ray_cap && k < base + n; ++k) rays[k] = 0xffffffffu;
+            fb_list[i] |= kFbOverflowFlag;
+            ovf_list[atomicAdd(ovf_count, 1u)] = i;
+            continue;
+        }
+        unsigned int k = base;
+        for (unsigned long long m = a0; m; m &= m - 1) rays[k++] = (i << 7) | (unsigned int)(__ffsll((long long)m) - 1);
+        for (unsigned long long m = a1; m; m &= m - 1) rays[k++] = (i << 7) | (64u + (unsigned int)(__ffsll((long long)m) - 1));
+    }
+}
+
+template <bool EXTRA, bool STATS>
+__global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
+                                                     const HitRec* __restrict__ hits, const unsigned int* __restrict__ fb_list,
+                                                     RoundState* __restrict__ state, const unsigned int* __restrict__ rays,
+                                                     unsigned int ray_cap, const unsigned int* __restrict__ ray_count,
+                                                     unsigned long long* stats) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
+    const unsigned int total = min(*ray_count, ray_cap);
+    const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
+    Ctr sec = {0, 0, 0, 0};
+    const unsigned int stride = gridDim.x * 256u;
+    for (unsigned int r = blockIdx.x * 256u + (unsigned)tid; r < total; r += stride) {
+        const unsigned int id = rays[r];
+        if (id == 0xffffffffu) continue;
+        const unsigned int i = id >> 7, j = id & 127u;
+        const HitRec rec = hits[fb_list[i] & ~kFbOverflowFlag];
+        const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
+        const D3 rs = lpos + mk(offsets[3 * j], offsets[3 * j + 1], offsets[3 * j + 2]);
+        const D3 rd = E - rs;
+        Hit h;
+        sec.rays++;
+        const bool blocked = root_intersect<MODE_BVH, true, EXTRA>(sc, sc.tris, sc.extra, st, rs, rd, h, sec) && !(h.t > 1.0);
+        if (blocked) atomicAnd(&state[i].escaped[j >> 6], ~(1ull << (j & 63u)));
+    }
+    if (STATS) {
+        uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom), c2 = wave_sum(sec.nodes), d2 = wave_sum(sec.leaves);
+        if (lane == 0) {
+            atomicAdd(&stats[4], (unsigned long long)a); atomicAdd(&stats[5], (unsigned long long)b);
+            atomicAdd(&stats[6], (unsigned long long)c2); atomicAdd(&stats[7], (unsigned long long)d2);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fb_resolve(FrameConst fc, const HitRec* __restrict__ hits, const unsigned int* __restrict__ count,
+                                                    const unsigned int* __restrict__ fb_list, const RoundState* __restrict__ state,
+                                                    uint32_t* __restrict__ samples) {
+    const unsigned int total = *count;
+    const unsigned int stride = gridDim.x * 256u;
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < total; i += stride) {
+        const unsigned int e = fb_list[i];
+        if (e & kFbOverflowFlag) continue;
+        const int esc = (int)__popcll(state[i].escaped[0]) + (int)__popcll(state[i].escaped[1]);
+        const uint32_t sample = hits[e].sample;
+        const double frac = (double)esc / (double)fc.shadow_samples;          // ShadowMethod.IntersectRay :113-119
+        samples[sample] = modulate(samples[sample], to_byte(frac * 255));
+    }
+}
+
 template <bool EXTRA, bool STATS>
 __global__ __launch_bounds__(256) void k_shadow_wave(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
                                                      const HitRec* __restrict__ hits, const unsigned int* __restrict__ count,
+                                                     const unsigned int* __restrict__ sub_list,
                                                      const unsigned int* __restrict__ index_list, const RoundState* __restrict__ state,
                                                      uint32_t* __restrict__ samples, unsigned long long* stats) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
     const int S = fc.shadow_samples;
-    const unsigned int total = *count;
+    const unsigned int total = *count;                 // entries of sub_list (indices into index_list / state)
     const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
     Ctr sec = {0, 0, 0, 0};
     const unsigned int nwaves = gridDim.x * 4u;
-    for (unsigned int i = blockIdx.x * 4u + (unsigned)wave; i < total; i += nwaves) {
-        const HitRec rec = hits[index_list[i]];
+    for (unsigned int k = blockIdx.x * 4u + (unsigned)wave; k < total; k += nwaves) {
+        const unsigned int i = sub_list[k];
+        const HitRec rec = hits[index_list[i] & ~kFbOverflowFlag];
         const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
         const RoundState stt = state[i];           // verdicts of the list rounds: only undecided samples are traced
         int esc = 0;
@@ -1008,10 +1103,24 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
     pipe_events(L, K_FALLBACK, e0, e1);
     if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
     {
+        // counters: [10] rays in the fallback ray list  [11] entries the list had no room for
+        unsigned int* ray_count = L.counters + 10;
+        unsigned int* ovf_count = L.counters + 11;
+        RoundState* fst = (RoundState*)L.fallback_state;
         size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
-        unsigned blocks = (unsigned)std::min<long long>((max_hits + 3) / 4, (long long)L.persistent_blocks * 2);
-        if (L.stats) hipLaunchKernelGGL((k_shadow_wave<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, fb_count, L.fallback, (const RoundState*)L.fallback_state, samples, L.stats);
-        else hipLaunchKernelGGL((k_shadow_wave<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, fb_count, L.fallback, (const RoundState*)L.fallback_state, samples, L.stats);
+        unsigned small = (unsigned)std::min<long long>((max_hits + 255) / 256, (long long)L.persistent_blocks);
+        hipLaunchKernelGGL(k_fb_expand, dim3(small), dim3(256), 0, L.stream, fb_count, L.fallback, (const RoundState*)fst, L.fallback_rays,
+                           L.fallback_ray_cap, ray_count, L.fallback_overflow, ovf_count);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        unsigned blocks = (unsigned)std::min<long long>(((long long)L.fallback_ray_cap + 255) / 256, (long long)L.persistent_blocks);
+        if (L.stats) hipLaunchKernelGGL((k_shadow_rays<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, L.fallback, fst, L.fallback_rays, L.fallback_ray_cap, ray_count, L.stats);
+        else hipLaunchKernelGGL((k_shadow_rays<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, L.fallback, fst, L.fallback_rays, L.fallback_ray_cap, ray_count, L.stats);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_fb_resolve, dim3(small), dim3(256), 0, L.stream, L.fc, (const HitRec*)L.hits, fb_count, L.fallback, (const RoundState*)fst, samples);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        unsigned wblocks = (unsigned)std::min<long long>((max_hits + 3) / 4, (long long)L.persistent_blocks * 2);
+        if (L.stats) hipLaunchKernelGGL((k_shadow_wave<EXTRA, true>), dim3(wblocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, ovf_count, L.fallback_overflow, L.fallback, (const RoundState*)fst, samples, L.stats);
+        else hipLaunchKernelGGL((k_shadow_wave<EXTRA, false>), dim3(wblocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, ovf_count, L.fallback_overflow, L.fallback, (const RoundState*)fst, samples, L.stats);
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
@@ -1028,7 +1137,7 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
         uint32_t* samples = (n2 == 1) ? L.pixels : L.samples;
         hipError_t e;
         if (shadows) {
-            e = hipMemsetAsync(L.counters, 0, 8 * sizeof(unsigned int), L.stream);
+            e = hipMemsetAsync(L.counters, 0, 16 * sizeof(unsigned int), L.stream);
             if (e != hipSuccess) return e;
         }
         hipEvent_t e0 = nullptr, e1 = nullptr;

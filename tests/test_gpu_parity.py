@@ -330,6 +330,11 @@ def test_pipeline_bands_rounds_and_fallback(monkeypatch):
     assert np.array_equal(got, want)
     c = g.debug_counters()
     assert c[2] > 0 and c[3] > 0, c            # round 2 and the fallback were really exercised
+    # the fallback's ray list too small for most entries: they take the one-wave-per-hit kernel instead
+    monkeypatch.setenv("SR_FB_RAY_CAP", "40")
+    got, _ = g.render(as_sr(f, sa.MODE_BVH))
+    assert np.array_equal(got, want)
+    monkeypatch.delenv("SR_FB_RAY_CAP")
     f2 = make_frame(96, 80, depth=1.5, shadows=True, sub_pixel_res=2, focal_blur=True)
     want2, _ = o.render(f2, threads=NCPU)
     got2, _ = g.render(as_sr(f2, sa.MODE_BVH))
