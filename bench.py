@@ -236,6 +236,21 @@ def main():
                 traffic = tj.get("%s_%d_%d_%d" % (args.mode, args.tris, args.res, args.shadows), {}).get(dom[0])
             except Exception:
                 traffic = None
+        # what actually bounds the kernels: SQ counters of the committed profile of this workload (separate rocprofv3 --pmc passes)
+        issue = None
+        spath = os.path.join(ROOT, "profiles", "r01d_pipeline", "sq_counters_summary.csv")
+        if os.path.exists(spath) and traffic is not None:
+            try:
+                import csv
+                issue = {"source": "profiles/r01d_pipeline/sq_counters_summary.csv (rocprofv3 --pmc SQ_*, same workload)",
+                         "valu_busy_frac": {}, "active_lanes_per_valu_inst": {}, "wait_any_frac_of_wave_cycles": {}}
+                for r in csv.DictReader(open(spath)):
+                    if r["kernel"] in ("k_primary", "k_shaft", "k_shadow_test"):
+                        issue["valu_busy_frac"][r["kernel"]] = float(r["valu_busy_frac_at_2.4GHz_1024_SIMDs"])
+                        issue["active_lanes_per_valu_inst"][r["kernel"]] = float(r["active_lanes_per_valu_inst"])
+                        issue["wait_any_frac_of_wave_cycles"][r["kernel"]] = float(r["SQ_WAIT_ANY"]) / float(r["SQ_WAVE_CYCLES"])
+            except Exception:
+                issue = None
         # PCIe-inclusive frame time (never `value`): one D2H of the frame
         t1 = time.perf_counter()
         local.cpu()
@@ -260,7 +275,7 @@ def main():
                          "launches_per_frame": sum(v[1] for k, v in kt.items() if fam(k) == dom[0]) / args.steps,
                          "all_kernels_ms_per_frame": fam_ms,
                          "all_kernels_algorithmic_GBs": {k: algo.get(k, 0.0) / (v * 1e-3) / 1e9 for k, v in fam_ms.items() if v > 0},
-                         "per_ray_touch_bytes_per_frame": per_ray_touch,
+                         "per_ray_touch_bytes_per_frame": per_ray_touch, "issue_bound": issue,
                          "note": "achieved = wave-granular algorithmic bytes of the dominant kernel family per frame / its device time per frame "
                                  "(HIP event pairs around every launch).  The scene (128 MB records + 21 MB BVH + 64 MB slabs) is cache "
                                  "resident and the kernels are FP64-issue / latency bound, not HBM bound; per_ray_touch is SURVEY 8d's "
