@@ -873,30 +873,119 @@ __global__ __launch_bounds__(256) void k_fb_expand(const unsigned int* __restric
     }
 }
 
+constexpr int kRaysRefillAt = 40;        // k_shadow_rays fetches new rays when at most this many lanes are still walking
+
+// Persistent lanes with refill: the rays of this list belong to different hit points and end after very different numbers
+// of steps (most are blocked early, the lit ones walk the whole ray), so with one ray per lane 8 of 64 lanes were busy on
+// average.  There is no coherence to lose here, unlike in k_shaft.  The walk is bvh_intersect<true> (sr_trace.h) unrolled
+// into a per-lane state machine: same clip, same rayFracOffset, same fp32 culling, same FP64 triangle test.
 template <bool EXTRA, bool STATS>
 __global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
                                                      const HitRec* __restrict__ hits, const unsigned int* __restrict__ fb_list,
                                                      RoundState* __restrict__ state, const unsigned int* __restrict__ rays,
                                                      unsigned int ray_cap, const unsigned int* __restrict__ ray_count,
-                                                     unsigned long long* stats) {
+                                                     unsigned int* __restrict__ ray_head, unsigned long long* stats) {
     const int tid = threadIdx.x, lane = tid & 63;
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
     const unsigned int total = min(*ray_count, ray_cap);
     const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
+    const float kInfl = 1.0f + 9.5367431640625e-7f;          // 1 + 2^-20
     Ctr sec = {0, 0, 0, 0};
-    const unsigned int stride = gridDim.x * 256u;
-    for (unsigned int r = blockIdx.x * 256u + (unsigned)tid; r < total; r += stride) {
-        const unsigned int id = rays[r];
-        if (id == 0xffffffffu) continue;
-        const unsigned int i = id >> 7, j = id & 127u;
-        const HitRec rec = hits[fb_list[i] & ~kFbOverflowFlag];
-        const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
-        const D3 rs = lpos + mk(offsets[3 * j], offsets[3 * j + 1], offsets[3 * j + 2]);
-        const D3 rd = E - rs;
-        Hit h;
-        sec.rays++;
-        const bool blocked = root_intersect<MODE_BVH, true, EXTRA>(sc, sc.tris, sc.extra, st, rs, rd, h, sec) && !(h.t > 1.0);
-        if (blocked) atomicAnd(&state[i].escaped[j >> 6], ~(1ull << (j & 63u)));
+    // ---- per ray ----
+    unsigned int ei = 0, ej = 0;           // fallback entry, sample
+    D3 s = mk(0, 0, 0), d = mk(0, 0, 0);
+    double offset = 0.0;
+    f2 I01 = splat(0.0f), I20 = I01, I12 = I01, B0 = I01, B1 = I01, B2 = I01;
+    float tlim = 0.0f;
+    int sp = 0;
+    int32_t ni = -1, leafA = -1, leafB = -1;
+    bool active = false;
+    bool drained = false;                  // wave-uniform: the head has passed the end of the list
+    for (;;) {
+        const unsigned long long busy = __ballot(active);
+        if (!drained && (int)__popcll(busy) <= kRaysRefillAt) {
+            const unsigned long long m = ~busy;
+            unsigned int base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(ray_head, (unsigned int)__popcll(m));
+            base = __shfl(base, leader, 64);
+            drained = base + (unsigned int)__popcll(m) >= total;
+            if (!active) {
+                const unsigned int r = base + (unsigned int)__popcll(m & lanemask_lt());
+                const unsigned int id = r < total ? rays[r] : 0xffffffffu;
+                if (id != 0xffffffffu) {
+                    ei = id >> 7; ej = id & 127u;
+                    const HitRec rec = hits[fb_list[ei] & ~kFbOverflowFlag];
+                    const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
+                    const D3 rs = lpos + mk(offsets[3 * ej], offsets[3 * ej + 1], offsets[3 * ej + 2]);
+                    const D3 rd = E - rs;
+                    sec.rays++;
+                    if (EXTRA && extras_block<EXTRA>(sc, rs, rd, sec)) {
+                        atomicAnd(&state[ei].escaped[ej >> 6], ~(1ull << (ej & 63u)));
+                    } else {
+                        s = rs; d = rd;
+                        D3 end = s + d * 10000.0;
+                        if (clip_segment<false>(sc.root, s, end)) {             // SpatialSubdivision.cs:394
+                            offset = length(rs - s) / length(d);                // :401
+                            const double lim = 1.0 - offset;                    // occluder <=> fl(t + offset) <= 1.0
+                            if (!(lim < 0.0)) {
+                                const float ox = (float)(s.x - sc.root.centre[0]), oy = (float)(s.y - sc.root.centre[1]), oz = (float)(s.z - sc.root.centre[2]);
+                                const float ix = slab_inv((float)d.x), iy = slab_inv((float)d.y), iz = slab_inv((float)d.z);
+                                I01 = (f2){ix, iy}; I20 = (f2){iz, ix}; I12 = (f2){iy, iz};
+                                B0 = (f2){-ox * ix, -oy * iy}; B1 = (f2){-oz * iz, -ox * ix}; B2 = (f2){-oy * iy, -oz * iz};
+                                tlim = (float)lim * kInfl + 1e-30f;
+                                sp = 0; ni = 0; leafA = -1; leafB = -1;
+                                active = true;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (!__any(active)) break;
+        if (active) {
+            while (ni >= 0 && leafA < 0) {
+                const BvhNode n = sc.bnodes[ni];
+                sec.nodes++;
+                float t0, x0, t1, x1;
+                node_slabs(n, I01, I20, I12, B0, B1, B2, t0, x0, t1, x1);
+                const bool h0 = n.n0 >= 0 && t0 <= x0 && x0 >= 0.0f && t0 <= tlim;
+                const bool h1 = n.n1 >= 0 && t1 <= x1 && x1 >= 0.0f && t1 <= tlim;
+                const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
+                if (l0 && l1) {                                   // nearer leaf first
+                    const bool first0 = t0 <= t1;
+                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << 28);
+                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << 28);
+                } else if (l0) leafA = n.c0 | (n.n0 << 28);
+                else if (l1) leafA = n.c1 | (n.n1 << 28);
+                const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
+                if (i0 && i1) {
+                    const bool first0 = t0 <= t1;
+                    st.put(sp++, first0 ? n.c1 : n.c0);
+                    ni = first0 ? n.c0 : n.c1;
+                } else if (i0) ni = n.c0;
+                else if (i1) ni = n.c1;
+                else ni = (sp > 0) ? st.get(--sp) : -1;
+            }
+            bool blocked = false;
+            while (leafA >= 0 && !blocked) {
+                const int32_t first = leafA & 0x0fffffff, cn = (leafA >> 28) & 7;
+                leafA = leafB;
+                leafB = -1;
+                sec.leaves++;
+                for (int k = first; k < first + cn && !blocked; ++k) {
+                    double t; D3 pos;
+                    sec.geom++;
+                    if (tri_hit(sc.btris[k].p, s, d, t, pos) && inside(sc.root.lo, sc.root.hi, pos) && (t + offset <= 1.0)) blocked = true;
+                }
+            }
+            if (blocked) {
+                atomicAnd(&state[ei].escaped[ej >> 6], ~(1ull << (ej & 63u)));
+                active = false;
+            } else if (ni < 0 && leafA < 0) {
+                active = false;                                   // walked the whole ray: the sample escapes
+            }
+        }
     }
     if (STATS) {
         uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom), c2 = wave_sum(sec.nodes), d2 = wave_sum(sec.leaves);
@@ -1103,7 +1192,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
     pipe_events(L, K_FALLBACK, e0, e1);
     if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
     {
-        // counters: [10] rays in the fallback ray list  [11] entries the list had no room for
+        // counters: [10] rays in the fallback ray list  [11] entries the list had no room for  [12] k_shadow_rays' work head
         unsigned int* ray_count = L.counters + 10;
         unsigned int* ovf_count = L.counters + 11;
         RoundState* fst = (RoundState*)L.fallback_state;
@@ -1113,8 +1202,8 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                            L.fallback_ray_cap, ray_count, L.fallback_overflow, ovf_count);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         unsigned blocks = (unsigned)std::min<long long>(((long long)L.fallback_ray_cap + 255) / 256, (long long)L.persistent_blocks);
-        if (L.stats) hipLaunchKernelGGL((k_shadow_rays<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, L.fallback, fst, L.fallback_rays, L.fallback_ray_cap, ray_count, L.stats);
-        else hipLaunchKernelGGL((k_shadow_rays<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, L.fallback, fst, L.fallback_rays, L.fallback_ray_cap, ray_count, L.stats);
+        if (L.stats) hipLaunchKernelGGL((k_shadow_rays<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, L.fallback, fst, L.fallback_rays, L.fallback_ray_cap, ray_count, L.counters + 12, L.stats);
+        else hipLaunchKernelGGL((k_shadow_rays<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, L.fallback, fst, L.fallback_rays, L.fallback_ray_cap, ray_count, L.counters + 12, L.stats);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         hipLaunchKernelGGL(k_fb_resolve, dim3(small), dim3(256), 0, L.stream, L.fc, (const HitRec*)L.hits, fb_count, L.fallback, (const RoundState*)fst, samples);
         if ((e = hipGetLastError()) != hipSuccess) return e;
