@@ -26,7 +26,7 @@ namespace Engine3D.Hip
     {
         public int width, height, start_row, end_row, sub_pixel_res;
         public uint background_argb, flags;
-        public int random_seed, shadow_samples, trace_mode, strip_rows, strip_count, strip_index, max_bounces;
+        public int random_seed, shadow_samples, trace_mode, strip_rows, strip_count, strip_index, max_bounces, concurrency, reserved0;
         [MarshalAs(UnmanagedType.ByValArray, SizeConst = 12)] public double[] transform;
         [MarshalAs(UnmanagedType.ByValArray, SizeConst = 12)] public double[] inv_transform;
         public double position_z, fov_depth, focal_depth, focal_blur_strength, ambient, shininess;
@@ -70,7 +70,7 @@ namespace Engine3D.Hip
     /// <summary>What Renderer.RaytraceGeometry hands to the device instead of the TPL fan-out over RaytraceBlock.</summary>
     public sealed class SoftrayHip : IDisposable
     {
-        public const uint F_SHADING = 1, F_SHADOWS = 2, F_FOCAL_BLUR = 4, F_POINT_LIGHT = 8, F_SPECULAR = 16;
+        public const uint F_SHADING = 1, F_SHADOWS = 2, F_FOCAL_BLUR = 4, F_POINT_LIGHT = 8, F_SPECULAR = 16, F_STATIC_SHADOWS = 32;
         public const int MODE_REF_TREE = 0, MODE_BRUTE = 1, MODE_BVH = 2;
         IntPtr scene;
         Model uploaded;
@@ -104,7 +104,7 @@ namespace Engine3D.Hip
         public void Render(int width, int height, int[] pixels, Instance instance, Matrix transform, Matrix inverseTransform,
                            uint backgroundColor, uint flags, int mode, int startRow, int endRow, int subPixelRes, int randomSeed,
                            double fieldOfViewDepth, double focalDepth, double focalBlurStrength, double ambient, double shininess,
-                           Vector lightDirView, Vector lightPosView, ulong[] stats4)
+                           Vector lightDirView, Vector lightPosView, ulong[] stats4, int concurrency = 4)
         {
             if (areaLightOffsets == null)
             {
@@ -122,6 +122,7 @@ namespace Engine3D.Hip
             {
                 width = width, height = height, start_row = startRow, end_row = endRow, sub_pixel_res = subPixelRes,
                 background_argb = backgroundColor, flags = flags, random_seed = randomSeed, shadow_samples = 0, trace_mode = mode,
+                concurrency = concurrency,                                   // rayTraceConcurrency: fill order of the static shadow cache
                 transform = new double[12], inv_transform = new double[12],
                 position_z = instance.Position.z, fov_depth = fieldOfViewDepth, focal_depth = focalDepth,
                 focal_blur_strength = focalBlurStrength, ambient = ambient, shininess = shininess,

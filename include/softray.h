@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 1
+#define SR_ABI_VERSION 2
 
 enum {
     SR_OK                 =  0,
@@ -55,6 +55,15 @@ enum {
     SR_F_FOCAL_BLUR  = 1u << 2,   /* rayTraceFocalBlur (only read when sub_pixel_res > 1, :1744-1790)   */
     SR_F_POINT_LIGHT = 1u << 3,   /* pointLighting   (Scene.cs:20)                                      */
     SR_F_SPECULAR    = 1u << 4,   /* specularLighting (Scene.cs:21)                                     */
+    SR_F_STATIC_SHADOWS = 1u << 5, /* rayTraceShadowsStatic, with SR_F_SHADOWS (ShadowMethod.cs:75-83,103-108): the light
+                                     fraction of a surface point is (byte)(fraction*254+1) looked up in a 128^3 texture over
+                                     the unit cube; an empty cell is generated for whoever asks first and then kept by the
+                                     scene for later frames (sr_reset_shadow_cache = a new Renderer).  The reference's worker
+                                     tasks race for the cells; the library uses the deterministic order that reproduces the
+                                     reference's goldens (RendererTests.RaytraceStaticShadow): the `concurrency` row blocks
+                                     advance in lock step -- row r of every block, blocks ascending, before row r + 1;
+                                     columns ascending; sub-samples in loop order.  Needs the whole frame in one call:
+                                     SR_ERR_UNSUPPORTED with strips, mirror bounces or SR_F_SINGLE_KERNEL            */
     SR_F_SINGLE_KERNEL = 1u << 8, /* library option, not a Renderer field: trace the frame with the one-kernel
                                      renderer (k_render) instead of the k_primary/k_shadow/k_resolve pipeline.
                                      Pixels are identical; kept as an independent cross-check               */
@@ -109,6 +118,9 @@ typedef struct {
                                         parity unpinned): mirror bounces r = dir - n*(2 dir.n) from pos + n*0.001,
                                         each level coloured by the same shading/shadow chain, colours blended per
                                         channel ((s*(255-k))>>8) + ((r*k)>>8), k = (byte)(reflectivity*255)       */
+    int32_t  concurrency;            /* rayTraceConcurrency (:92), <= 0 => 4.  Only read with SR_F_STATIC_SHADOWS: it fixes
+                                        the order in which the shadow cache is filled (see that flag)               */
+    int32_t  reserved0;              /* 0 */
     double   transform[12];          /* rows 0..2 of Instance._transform        (Instance.cs:134)        */
     double   inv_transform[12];      /* rows 0..2 of Instance._inverseTransform (Instance.cs:135)        */
     double   position_z;             /* Instance.Position.z (:1717, Instance.cs:182)                     */
@@ -157,6 +169,8 @@ int  sr_tree_stats(const sr_scene*, int32_t out[4]);
  * NumNodeVisits, NumLeafNodeVisits (Renderer.cs:465-504) summed over the frame's PRIMARY rays
  * (deterministic, unlike the reference's racy per-block counters, :1695). */
 int  sr_render(sr_scene*, const sr_frame*, int32_t* pixels, uint64_t stats[4]);
+/* forget the static shadow cache (what a new Renderer / ShadowMethod starts with); sr_set_triangles does it too */
+int  sr_reset_shadow_cache(sr_scene*);
 /* Same, but `d_pixels` is DEVICE memory on the scene's device (e.g. a torch tensor's data_ptr) and the
  * work is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream) without host sync. */
 int  sr_render_device(sr_scene*, const sr_frame*, void* d_pixels, void* hip_stream, uint64_t* d_stats /* device uint64[12] (see sr_last_ray_stats) or NULL */);

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
-F_SHADING, F_SHADOWS, F_FOCAL_BLUR, F_POINT_LIGHT, F_SPECULAR = 1, 2, 4, 8, 16
+F_SHADING, F_SHADOWS, F_FOCAL_BLUR, F_POINT_LIGHT, F_SPECULAR, F_STATIC_SHADOWS = 1, 2, 4, 8, 16, 32
 MODE_REF_TREE, MODE_BRUTE, MODE_NEAREST = 0, 1, 2
 
 
@@ -33,6 +33,7 @@ class Frame(C.Structure):
         ("trace_mode", C.c_int32),
         ("strip_rows", C.c_int32), ("strip_count", C.c_int32), ("strip_index", C.c_int32),
         ("max_bounces", C.c_int32),
+        ("concurrency", C.c_int32), ("reserved0", C.c_int32),
         ("transform", C.c_double * 12),
         ("inv_transform", C.c_double * 12),
         ("position_z", C.c_double),
@@ -77,6 +78,7 @@ def lib():
         L.orc_scene_set_extra.restype = i32; L.orc_scene_set_extra.argtypes = [vp, vp, i32]
         L.orc_scene_build_tree.restype = i32; L.orc_scene_build_tree.argtypes = [vp, i32, i32]
         L.orc_scene_tree_stats.argtypes = [vp, vp]
+        L.orc_scene_reset_shadow_cache.argtypes = [vp]
         L.orc_render.restype = i32; L.orc_render.argtypes = [vp, vp, vp, vp, i32]
         L.orc_trace.restype = i32
         L.orc_trace.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -196,6 +198,9 @@ class Scene:
 
     def build_tree(self, max_depth=15, max_per_leaf=25):
         return lib().orc_scene_build_tree(self._h, max_depth, max_per_leaf)
+
+    def reset_shadow_cache(self):
+        lib().orc_scene_reset_shadow_cache(self._h)
 
     def tree_stats(self):
         out = np.zeros(4, dtype=np.int32)

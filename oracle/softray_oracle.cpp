@@ -604,6 +604,7 @@ struct orc_scene {
     std::vector<Plane> planes;
     std::vector<Triangle> extraTris;
     std::vector<int> extraIdx;
+    std::vector<uint8_t> staticCache;    /* ShadowMethod's Texture3DCache<byte>(128): empty until the first static frame */
 };
 
 namespace {
@@ -714,6 +715,9 @@ struct FrameCtx {
     std::vector<Vec> areaLightOffsets;
     int shadowSamples;
     int mode;
+    /* static soft-shadow cache (ShadowMethod.cs:75-83, Texture3DCache.cs:95-135), 128^3 bytes, 0 = empty; owned by
+     * the scene (it outlives a frame, like the reference's ShadowMethod), filled in the order orc_render defines */
+    std::vector<uint8_t>* staticCache;
 };
 
 /* ShadowMethod.TraceRaysForSoftShadows (ShadowMethod.cs:144-179).  The reference traces shadow rays
@@ -758,7 +762,19 @@ uint32_t ChainColor(const FrameCtx& fc, const Hit& info0, Counters& secondary) {
         uint8_t lightIntensityByte = ToByte(255 * intensity);
         info.color = ModulatePackedColor(info.color, lightIntensityByte);
     }
-    if (fc.f->flags & ORC_F_SHADOWS) {                          /* ShadowMethod.IntersectRay :93-121 */
+    if ((fc.f->flags & ORC_F_SHADOWS) && (fc.f->flags & ORC_F_STATIC_SHADOWS)) {
+        const int n = 128;                                      /* staticShadowRes, Renderer.cs:114 */
+        auto cell = [&](double v) { int k = (int)((v + 0.5) * (n - 1)); return std::min(std::max(k, 0), n - 1); };
+        size_t idx = (size_t)cell(info.pos.x) * n * n + (size_t)cell(info.pos.y) * n + (size_t)cell(info.pos.z);   /* Texture3DCache.cs:102-104 */
+        uint8_t sample = (*fc.staticCache)[idx];
+        if (sample == 0) {
+            double v = TraceRaysForSoftShadows(fc, info.pos, info.normal, secondary) * 254 + 1;   /* ShadowMethod.cs:80 */
+            sample = (uint8_t)(int)v;
+            if (sample == 0) sample = 1;
+            (*fc.staticCache)[idx] = sample;
+        }
+        info.color = ModulatePackedColor(info.color, sample);
+    } else if (fc.f->flags & ORC_F_SHADOWS) {                   /* ShadowMethod.IntersectRay :93-121 */
         uint8_t lightIntensityByte = ToByte(TraceRaysForSoftShadows(fc, info.pos, info.normal, secondary) * 255);
         info.color = ModulatePackedColor(info.color, lightIntensityByte);
     }
@@ -899,8 +915,11 @@ void orc_random_next_doubles(orc_random* r, int64_t n, double* out) { for (int64
 orc_scene* orc_scene_new(void) { return new orc_scene(); }
 void orc_scene_free(orc_scene* s) { delete s; }
 
+void orc_scene_reset_shadow_cache(orc_scene* s) { if (s) s->staticCache.clear(); }
+
 int orc_scene_set_triangles(orc_scene* s, const double* v9, const uint32_t* argb, int64_t n,
                             const double box_min[3], const double box_max[3]) {
+    s->staticCache.clear();                                     /* new model: new renderer state */
     s->tris.clear();
     s->tris.reserve((size_t)n);
     for (int64_t i = 0; i < n; i++) {
@@ -1024,6 +1043,13 @@ int orc_render(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t
     Vec start_World = fc.xf.TransformDirectionReverse(V(0, 0, -fc.xf.positionZ));   /* Renderer.cs:1717 */
 
     int nthreads = threads > 0 ? threads : 1;
+    if (f->flags & ORC_F_STATIC_SHADOWS) {
+        if (f->max_bounces > 0 || f->strip_count > 1) return -7;    /* not defined for the bounce extension / a split frame */
+        orc_scene* ms = const_cast<orc_scene*>(s);                  /* the cache is renderer state */
+        if (ms->staticCache.empty()) ms->staticCache.assign((size_t)128 * 128 * 128, 0);
+        fc.staticCache = &ms->staticCache;
+        nthreads = 1;
+    }
     /* work items = 64-pixel chunks of a row (the reference fans out row BLOCKS, Renderer.cs:1659-1670; pixels are
      * independent, so the partition does not change any pixel) */
     const int chunk = 64;
@@ -1043,7 +1069,27 @@ int orc_render(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t
                 dst[col] = (int32_t)RenderPixel(fc, col, row, start_World, prim[tid], sec[tid], rays[tid]);
         }
     };
-    if (nthreads == 1) {
+    if (f->flags & ORC_F_STATIC_SHADOWS) {
+        /* rayTraceShadowsStatic.  The reference fills the cache from rayTraceConcurrency row-block tasks that race
+         * (Renderer.cs:1659-1670, Texture3DCache.cs:117-135; its own test notes that the thread count changes pixels).
+         * Deterministic definition used here, PINNED by the two goldens of RendererTests.RaytraceStaticShadow
+         * (shading_staticShadows.bmp, noShading_staticShadows.bmp, 0 differing pixels; plain scan order differs in 9
+         * pixels, all on the block seams): the tasks advance in lockstep -- row r of every block, blocks in ascending
+         * order, before row r + 1; columns ascending inside a row -- and a cell keeps the value computed for its
+         * first requester. */
+        const int conc = f->concurrency > 0 ? f->concurrency : 4;   /* Renderer.cs:92 */
+        const int numRows = (int)rows.size();
+        const int blockHeight = (numRows - 1 + conc) / conc;        /* :1661 */
+        for (int r = 0; r < blockHeight; r++)
+            for (int b = 0; b * blockHeight < numRows; b++) {
+                const int i = b * blockHeight + r;
+                if (i >= numRows) continue;
+                const int row = rows[i];
+                int32_t* dst = (f->strip_count > 0) ? pixels + (size_t)i * f->width : pixels + (size_t)row * f->width;
+                for (int col = 0; col < f->width; col++)
+                    dst[col] = (int32_t)RenderPixel(fc, col, row, start_World, prim[0], sec[0], rays[0]);
+            }
+    } else if (nthreads == 1) {
         worker(0);
     } else {
         std::vector<std::thread> th;

@@ -57,6 +57,8 @@ typedef struct {
     int32_t  trace_mode;             /* ORC_MODE_*                                              */
     int32_t  strip_rows, strip_count, strip_index; /* multi-GPU row interleave; 0 => off        */
     int32_t  max_bounces;            /* config-5 extension (mirror reflection); 0 => off        */
+    int32_t  concurrency;            /* rayTraceConcurrency, <= 0 => 4; read with ORC_F_STATIC_SHADOWS */
+    int32_t  reserved0;
     double   transform[12];          /* Instance._transform rows 0..2 (Instance.cs:134)         */
     double   inv_transform[12];      /* Instance._inverseTransform rows 0..2 (Instance.cs:135)  */
     double   position_z;             /* Instance.Position.z                                     */
@@ -73,7 +75,9 @@ enum {
     ORC_F_SHADOWS     = 1u << 1,     /* rayTraceShadows (dynamic)  */
     ORC_F_FOCAL_BLUR  = 1u << 2,     /* rayTraceFocalBlur    */
     ORC_F_POINT_LIGHT = 1u << 3,     /* pointLighting        */
-    ORC_F_SPECULAR    = 1u << 4      /* specularLighting     */
+    ORC_F_SPECULAR    = 1u << 4,     /* specularLighting     */
+    ORC_F_STATIC_SHADOWS = 1u << 5   /* rayTraceShadowsStatic (with ORC_F_SHADOWS): 128^3 cache kept by the scene, filled in
+                                        the lock-step row-block order defined in orc_render */
 };
 enum {
     ORC_MODE_REF_TREE = 0,  /* SpatialSubdivision.IntersectRay, literal                          */
@@ -92,6 +96,7 @@ int  orc_scene_set_extra(orc_scene*, const orc_prim* prims, int32_t n);
 int  orc_scene_build_tree(orc_scene*, int32_t max_depth, int32_t max_per_leaf);
 /* out = TreeDepth, NumNodes, NumLeafNodes, NumInternalNodes */
 void orc_scene_tree_stats(const orc_scene*, int32_t out[4]);
+void orc_scene_reset_shadow_cache(orc_scene*);   /* a new Renderer / ShadowMethod: empty static shadow cache */
 
 /* Renderer.Render() for one Instance (raytrace path).  pixels = int[W*H] ARGB (strip-compact if
  * strip_count>0).  stats = rays fired, geometry tests, node visits, leaf visits (primary rays;

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SR_OK = 0
 SR_ERR_INVALID_ARG, SR_ERR_OUT_OF_RANGE, SR_ERR_NO_MODEL, SR_ERR_NOT_BUILT = -1, -2, -3, -4
 SR_ERR_UNSUPPORTED, SR_ERR_NO_DEVICE, SR_ERR_HIP, SR_ERR_FORMAT = -5, -6, -7, -8
-F_SHADING, F_SHADOWS, F_FOCAL_BLUR, F_POINT_LIGHT, F_SPECULAR = 1, 2, 4, 8, 16
+F_SHADING, F_SHADOWS, F_FOCAL_BLUR, F_POINT_LIGHT, F_SPECULAR, F_STATIC_SHADOWS = 1, 2, 4, 8, 16, 32
 F_SINGLE_KERNEL = 1 << 8
 F_PER_LANE_SHADOWS = 1 << 9
 MODE_REF_TREE, MODE_BRUTE, MODE_BVH = 0, 1, 2
@@ -28,7 +28,7 @@ SYMBOLS = [
     "sr_render", "sr_render_device", "sr_frame_pixel_count", "sr_trace_rays", "sr_instance_matrices",
     "sr_default_fov_depth", "sr_area_light_offsets", "sr_load_3ds", "sr_num_triangles", "sr_get_triangles",
     "sr_reset_kernel_times", "sr_kernel_times", "sr_last_ray_stats", "sr_make_random_triangles", "sr_debug_counters", "sr_last_error", "sr_abi_version",
-    "sr_post_process", "sr_post_process_device", "sr_anti_alias", "sr_anti_alias_device",
+    "sr_post_process", "sr_post_process_device", "sr_anti_alias", "sr_anti_alias_device", "sr_reset_shadow_cache",
 ]
 
 
@@ -49,6 +49,7 @@ class Frame(C.Structure):
         ("trace_mode", C.c_int32),
         ("strip_rows", C.c_int32), ("strip_count", C.c_int32), ("strip_index", C.c_int32),
         ("max_bounces", C.c_int32),
+        ("concurrency", C.c_int32), ("reserved0", C.c_int32),
         ("transform", C.c_double * 12),
         ("inv_transform", C.c_double * 12),
         ("position_z", C.c_double),
@@ -119,6 +120,7 @@ def lib():
     L.sr_post_process_device.restype = i32; L.sr_post_process_device.argtypes = [vp, vp, i64, i32, u32, vp]
     L.sr_anti_alias.restype = i32; L.sr_anti_alias.argtypes = [vp, vp, i32, i32, i32, vp]
     L.sr_anti_alias_device.restype = i32; L.sr_anti_alias_device.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.sr_reset_shadow_cache.restype = i32; L.sr_reset_shadow_cache.argtypes = [vp]
     L.sr_last_error.restype = C.c_char_p; L.sr_last_error.argtypes = []
     L.sr_abi_version.restype = i32; L.sr_abi_version.argtypes = []
     _lib = L

@@ -74,6 +74,8 @@ struct sr_scene {
     size_t      bvh_num_nodes = 0;
     // device state
     DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab;
+    DBuf d_shadow_cache, d_static_claim, d_static_hits;
+    bool shadow_cache_empty = true;      // the device cache must be zeroed before its next use
     DBuf d_offsets, d_rowmap, d_pixels, d_aa, d_stats, d_io[9], d_hits, d_samples, d_counters, d_fallback, d_fallback_state, d_fallback_rays, d_fallback_ovf, d_rlist[sr::kShaftRounds], d_rstate[sr::kShaftRounds], d_rcount[sr::kShaftRounds], d_rcand[sr::kShaftRounds];
     int num_cus = 0;
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
@@ -130,6 +132,7 @@ sr::DevScene dev_scene(const sr_scene* s) {
     d.bnode_bits = 1;
     while ((1ull << d.bnode_bits) < s->bvh_num_nodes + 1 && d.bnode_bits < 26) d.bnode_bits++;
     d.root = s->root;
+    d.shadow_cache = (uint8_t*)s->d_shadow_cache.p;
     return d;
 }
 
@@ -243,6 +246,19 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     if (!s->rowmap_host.empty())
         SR_HIP(hipMemcpyAsync(s->d_rowmap.p, s->rowmap_host.data(), s->rowmap_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     if (fc.num_rows == 0) return SR_OK;
+    const bool static_shadows = (f->flags & SR_F_STATIC_SHADOWS) && (f->flags & SR_F_SHADOWS);
+    if (static_shadows) {
+        if ((f->flags & SR_F_SINGLE_KERNEL) || f->max_bounces > 0 || f->strip_count > 1)
+            return fail(SR_ERR_UNSUPPORTED, "static shadows need the whole frame in one pipeline call (no strips, mirror bounces or SR_F_SINGLE_KERNEL)");
+        SR_HIP(s->d_shadow_cache.reserve(sr::pipeline_static_cells()));
+        SR_HIP(s->d_static_claim.reserve(sr::pipeline_static_cells() * 8));
+        if (s->shadow_cache_empty) {
+            SR_HIP(hipMemsetAsync(s->d_shadow_cache.p, 0, sr::pipeline_static_cells(), stream));
+            s->shadow_cache_empty = false;
+        }
+    } else {
+        fc.flags &= ~(uint32_t)SR_F_STATIC_SHADOWS;          // meaningless without SR_F_SHADOWS (RendererTests.cs:420)
+    }
     if ((f->flags & SR_F_SINGLE_KERNEL) || f->max_bounces > 0) {      // mirror bounces: the one-kernel renderer traces them inline
         sr::RenderLaunch L{};
         L.sc = dev_scene(s);
@@ -279,6 +295,10 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     band_rows = std::min<long long>(band_rows, ((long long)fc.num_rows + 15) / 16 * 16);
     const long long band_samples = band_rows * fc.width * n2;
     if (shadows) SR_HIP(s->d_hits.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
+    if (static_shadows) {
+        if (band_rows < fc.num_rows) return fail(SR_ERR_UNSUPPORTED, "static shadows: the frame does not fit one row band");
+        SR_HIP(s->d_static_hits.reserve((size_t)std::min<long long>(band_samples, (long long)sr::pipeline_static_cells()) * sr::pipeline_hit_record_bytes()));
+    }
     // fallback ray list: one 32-bit id (entry << 7 | sample; bands have < 2^25 entries) per undecided sample.  6 per band
     // sample = 0.4 GB for a 4096^2 band; whatever it has no room for is taken by the one-wave-per-hit kernel.  Test hook
     // SR_FB_RAY_CAP shrinks it
@@ -316,6 +336,9 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     P.samples = (uint32_t*)s->d_samples.p;
     P.hits = s->d_hits.p;
     P.counters = (unsigned int*)s->d_counters.p;
+    P.static_hits = static_shadows ? s->d_static_hits.p : nullptr;
+    P.static_claim = static_shadows ? (unsigned long long*)s->d_static_claim.p : nullptr;
+    P.static_concurrency = f->concurrency;
     P.fallback = shaft ? (unsigned int*)s->d_fallback.p : nullptr;
     P.fallback_state = shaft ? s->d_fallback_state.p : nullptr;
     P.fallback_rays = shaft ? (unsigned int*)s->d_fallback_rays.p : nullptr;
@@ -373,7 +396,7 @@ void sr_destroy(sr_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
-                        &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_fallback, &s->d_fallback_state, &s->d_fallback_rays, &s->d_fallback_ovf};
+                        &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_fallback, &s->d_fallback_state, &s->d_fallback_rays, &s->d_fallback_ovf};
         for (DBuf* b : bufs) b->release();
         for (int r = 0; r < sr::kShaftRounds; ++r) { s->d_rlist[r].release(); s->d_rstate[r].release(); s->d_rcount[r].release(); s->d_rcand[r].release(); }
         for (DBuf& b : s->d_io) b.release();
@@ -386,6 +409,7 @@ void sr_destroy(sr_scene* s) {
 int sr_set_triangles(sr_scene* s, const double* v9, const uint32_t* argb, int64_t n, const double box_min[3], const double box_max[3]) {
     if (!s || n < 0 || (n > 0 && (!v9 || !argb)) || !box_min || !box_max) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_set_triangles");
     if (n > 0x7fffff00) return fail(SR_ERR_INVALID_ARG, "too many triangles");
+    s->shadow_cache_empty = true;                         // new model: what a new ShadowMethod starts with
     s->v9.assign(v9, v9 + 9 * n);
     s->argb.assign(argb, argb + n);
     for (int a = 0; a < 3; ++a) { s->bmin[a] = box_min[a]; s->bmax[a] = box_max[a]; }
@@ -501,6 +525,12 @@ int64_t sr_frame_pixel_count(const sr_frame* f) {
     int64_t rows = 0;
     for (int r = a; r <= b; ++r) if (row_owned(f, r)) rows++;
     return rows * f->width;
+}
+
+int sr_reset_shadow_cache(sr_scene* s) {
+    if (!s) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_reset_shadow_cache");
+    s->shadow_cache_empty = true;
+    return SR_OK;
 }
 
 int sr_render_device(sr_scene* s, const sr_frame* f, void* d_pixels, void* hip_stream, uint64_t* d_stats) {

@@ -25,6 +25,7 @@ struct DevScene {
     int32_t        bdepth;
     int32_t        bnode_bits;  // bits needed for a BVH node index (stack words pack node | bound)
     RootBox        root;
+    uint8_t*       shadow_cache; // static soft-shadow cache, 128^3 bytes, 0 = empty cell (SR_F_STATIC_SHADOWS frames)
 };
 
 constexpr int kShaftRounds = 2;
@@ -63,6 +64,9 @@ struct PipelineLaunch {
     void*         round_state[kShaftRounds];      // device RoundState per item (round 0: nullptr)
     unsigned int* round_cand_count[kShaftRounds]; // device per-item candidate count | truncated flag
     int32_t*      round_cand[kShaftRounds];       // device [items][pipeline_round_cap(round)] (round_cand[0] == nullptr: no shaft path)
+    void*         static_hits;  // device HitRec[min(band samples, 128^3)]: generators of a static-shadow frame
+    unsigned long long* static_claim; // device [128^3]: smallest order key that asked for an empty cell
+    int32_t       static_concurrency; // rayTraceConcurrency of the frame
     unsigned int* fallback;     // device [band samples]: hits that need the exact per-lane fallback
     void*         fallback_state; // device RoundState per fallback entry: which samples are still undecided
     unsigned int* fallback_rays;  // device [fallback_ray_cap]: (entry << 7 | sample) of every undecided sample
@@ -78,6 +82,7 @@ struct PipelineLaunch {
 };
 hipError_t launch_pipeline(const PipelineLaunch& L);
 size_t pipeline_hit_record_bytes();
+size_t pipeline_static_cells();
 int pipeline_round_cap(int round);
 size_t pipeline_round_state_bytes();
 

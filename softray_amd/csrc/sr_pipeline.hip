@@ -24,9 +24,23 @@ struct alignas(16) HitRec {
     double   pos[3];
     double   nrm[3];
     uint32_t sample;     // index into the sample-colour buffer
-    uint32_t pad[3];
+    uint32_t pad[3];     // pad[0]: cell of the static shadow cache (generator hits of a static frame)
 };
 static_assert(sizeof(HitRec) == 64, "HitRec must be 64 bytes");
+
+// ShadowMethod.IntersectRay's last step for one surface point (ShadowMethod.cs:103-119): dynamic shadows modulate the
+// shaded colour with (byte)(fraction * 255); a static frame (SR_F_STATIC_SHADOWS) runs the shadow kernels only on the
+// hit points that generate a cache cell and stores (byte)(fraction * 254 + 1) there (ShadowMethod.cs:80, 0 = empty cell;
+// Texture3DCache.cs:124-126 replaces a generated 0 by 1) -- k_static_apply modulates every hit point afterwards.
+__device__ __forceinline__ void finish_hit(const DevScene& sc, const FrameConst& fc, uint32_t* samples, uint32_t sample, uint32_t cell,
+                                           uint32_t shaded, double frac) {
+    if (fc.flags & 32u) {
+        uint32_t v = (uint32_t)(int)(frac * 254 + 1) & 0xffu;
+        sc.shadow_cache[cell] = (uint8_t)(v ? v : 1u);
+    } else {
+        samples[sample] = modulate(shaded, to_byte(frac * 255));
+    }
+}
 
 __device__ __forceinline__ unsigned long long lanemask_lt() {
     unsigned lane = threadIdx.x & 63u;
@@ -175,7 +189,7 @@ __global__ __launch_bounds__(256) void k_shadow(DevScene sc, FrameConst fc, cons
     int i = S;                       // next sample of the current hit; S = lane needs a new hit
     int escapes = 0;
     int32_t cache = -1;              // record position of the last occluder found for this lane
-    uint32_t sample = 0;
+    uint32_t sample = 0, cell = 0;
     D3 shadowEnd = mk(0, 0, 0);
     bool exhausted = false;
 
@@ -195,6 +209,7 @@ __global__ __launch_bounds__(256) void k_shadow(DevScene sc, FrameConst fc, cons
                     D3 pos = mk(r.pos[0], r.pos[1], r.pos[2]), nrm = mk(r.nrm[0], r.nrm[1], r.nrm[2]);
                     shadowEnd = pos + nrm * 0.001;                       // shadowProbeOffset, ShadowMethod.cs:10,151
                     sample = r.sample;
+                    cell = r.pad[0];
                     i = 0;
                     escapes = 0;
                     // the cache is deliberately kept across hits: neighbouring surface points share occluders
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(256) void k_shadow(DevScene sc, FrameConst fc, cons
             }
             if (i >= S) {                                                 // ShadowMethod.IntersectRay :113-119
                 double frac = (double)escapes / (double)S;
-                samples[sample] = modulate(samples[sample], to_byte(frac * 255));
+                finish_hit(sc, fc, samples, sample, cell, (fc.flags & 32u) ? 0u : samples[sample], frac);
             }
         }
     }
@@ -328,6 +343,7 @@ constexpr int kRecStride16 = 9;          // record stride in 16-byte units (128 
 constexpr int kRayStride8 = 10;          // ray stride in doubles (7 used)
 constexpr int kTailSlots = 64;           // k_shadow_test switches to (sample x candidate) lanes once this few samples are undecided
 constexpr unsigned kTruncated = 0x80000000u;
+constexpr unsigned kUmbraItem = 0x40000000u;   // cand_count of a later round: k_shaft found an umbra triangle
 
 // The shaft is parametrised from the surface end: C(u) = E' + u (L - E'), u in [0, 1] (u = 1 - t), so that all fp32
 // quantities are small near the surface point (robust for distant lights); sample rays deviate from C(u) by at most
@@ -513,15 +529,18 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
             }
             if (truncated || umbra) break;
         }
-        if (umbra) {
+        if (umbra && !work_list) {
+            // later round: k_shadow_test owns the hit point's sample masks and finishes it -- every undecided sample is blocked
+            cand_count[slot_i] = kUmbraItem;
+        } else if (umbra) {
             // fully shadowed: rayEscapeCount = 0 -> (byte)(0.0 * 255) = 0 -> ModulatePackedColor(color, 0) = opaque black
-            samples[rec.sample] = modulate(samples[rec.sample], 0u);
+            finish_hit(sc, fc, samples, rec.sample, rec.pad[0], (fc.flags & 32u) ? 0u : samples[rec.sample], 0.0);
             cand_count[slot_i] = 0u;
             if (fc.debug == 7) atomicAdd(dbg + 7, 1u);
         } else if (work_list && count == 0 && !truncated && sc.nextra == 0) {
             // first round, nothing in the whole shaft and no extra geometry: every sample escapes,
             // rayEscapeCount = S -> (byte)(1.0 * 255) = 255 (ShadowMethod.cs:113-119); the pixel is finished here
-            samples[rec.sample] = modulate(samples[rec.sample], to_byte((double)fc.shadow_samples / (double)fc.shadow_samples * 255));
+            finish_hit(sc, fc, samples, rec.sample, rec.pad[0], (fc.flags & 32u) ? 0u : samples[rec.sample], (double)fc.shadow_samples / (double)fc.shadow_samples);
             cand_count[slot_i] = 0u;
         } else {
             cand_count[slot_i] = (unsigned)max(count, 0) | (truncated ? kTruncated : 0u);
@@ -614,7 +633,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
         }
         // the pixel's shaded colour is needed only when the item is finished: fetch it now, off the critical path
         uint32_t shaded = 0;
-        if (lane == 0) shaded = samples[rec.sample];
+        if (lane == 0 && !(fc.flags & 32u)) shaded = samples[rec.sample];
         // ---- (b) prefetch the next item ----
         {
             const unsigned int sn = slot_i + nwaves, snn = sn + nwaves;
@@ -638,7 +657,8 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
             escaped[k] = valid[k];
             if (state_in) {                                               // later round: resume from the saved masks
                 const RoundState stt = state_in[slot_i];
-                escaped[k] = ((stt.escaped[k] >> lane) & 1ull) != 0;
+                // (an undecided sample carries its escaped bit; an umbra triangle found by this round's walk blocks them all)
+                escaped[k] = ((stt.escaped[k] >> lane) & 1ull) != 0 && !(cc & kUmbraItem);
                 if (work && ((stt.alive[k] >> lane) & 1ull) != 0) alive[k] = prepare_sample(sc, rs, rd, ray[k]);
             } else if (valid[k]) {
                 sec.rays++;
@@ -810,7 +830,7 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
             const int esc = (int)__popcll(__ballot(escaped[0])) + (int)__popcll(__ballot(escaped[1]));
             if (lane == 0) {
                 double frac = (double)esc / (double)S;                     // ShadowMethod.IntersectRay :113-119
-                samples[rec.sample] = modulate(shaded, to_byte(frac * 255));
+                finish_hit(sc, fc, samples, rec.sample, rec.pad[0], shaded, frac);
             }
         }
     }
@@ -996,7 +1016,7 @@ __global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc,
     }
 }
 
-__global__ __launch_bounds__(256) void k_fb_resolve(FrameConst fc, const HitRec* __restrict__ hits, const unsigned int* __restrict__ count,
+__global__ __launch_bounds__(256) void k_fb_resolve(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits, const unsigned int* __restrict__ count,
                                                     const unsigned int* __restrict__ fb_list, const RoundState* __restrict__ state,
                                                     uint32_t* __restrict__ samples) {
     const unsigned int total = *count;
@@ -1007,7 +1027,7 @@ __global__ __launch_bounds__(256) void k_fb_resolve(FrameConst fc, const HitRec*
         const int esc = (int)__popcll(state[i].escaped[0]) + (int)__popcll(state[i].escaped[1]);
         const uint32_t sample = hits[e].sample;
         const double frac = (double)esc / (double)fc.shadow_samples;          // ShadowMethod.IntersectRay :113-119
-        samples[sample] = modulate(samples[sample], to_byte(frac * 255));
+        finish_hit(sc, fc, samples, sample, hits[e].pad[0], (fc.flags & 32u) ? 0u : samples[sample], frac);
     }
 }
 
@@ -1045,7 +1065,7 @@ __global__ __launch_bounds__(256) void k_shadow_wave(DevScene sc, FrameConst fc,
         esc = (int)wave_sum((uint32_t)esc);
         if (lane == 0) {
             double frac = (double)esc / (double)S;
-            samples[rec.sample] = modulate(samples[rec.sample], to_byte(frac * 255));
+            finish_hit(sc, fc, samples, rec.sample, rec.pad[0], (fc.flags & 32u) ? 0u : samples[rec.sample], frac);
         }
     }
     if (STATS) {
@@ -1078,6 +1098,67 @@ __global__ __launch_bounds__(256) void k_resolve(FrameConst fc, const int32_t* _
     sumR /= n2; sumG /= n2; sumB /= n2;
     pixels[(size_t)out_row * fc.width + col] =
         (255u << 24) + ((uint32_t)(sumR & 0xff) << 16) + ((uint32_t)(sumG & 0xff) << 8) + (uint32_t)(sumB & 0xff);   // Surface.PackRgb
+}
+
+// --------------------------------------------------------------------------------------------------
+// rayTraceShadowsStatic (ShadowMethod.cs:75-83,103-108, Texture3DCache.cs:95-135): the light fraction of a surface
+// point is looked up in a 128^3 byte texture over the unit cube; an empty cell is generated by whoever asks first.
+// The reference's worker tasks race for that; the CPU checker pins a deterministic order against the reference's two
+// goldens (row r of every row block, blocks ascending, before row r + 1; columns ascending; sub-samples in loop order)
+// and these three kernels reproduce it: every hit point claims its cell with an atomicMin on its order key, the
+// winners become the generator list that the ordinary shadow kernels process (they store the cell byte instead of
+// touching the pixel, see finish_hit), then every hit point modulates its sample with its cell.
+// --------------------------------------------------------------------------------------------------
+constexpr int kStaticRes = 128;          // staticShadowRes, Renderer.cs:114
+
+__device__ __forceinline__ uint32_t static_cell(const double* pos) {
+    const int n = kStaticRes;
+    int kx = (int)((pos[0] + 0.5) * (n - 1)), ky = (int)((pos[1] + 0.5) * (n - 1)), kz = (int)((pos[2] + 0.5) * (n - 1));   // Texture3DCache.cs:102-104
+    kx = min(max(kx, 0), n - 1); ky = min(max(ky, 0), n - 1); kz = min(max(kz, 0), n - 1);                              // the asserts of :99-101, clamped
+    return (uint32_t)((kx * n + ky) * n + kz);
+}
+// order key of a sample: ((row-in-block * blocks + block) * width + col) * n2 + sub-sample
+__device__ __forceinline__ unsigned long long static_key(const FrameConst& fc, uint32_t sample, int block_height, int nblocks) {
+    const unsigned int n2 = (unsigned int)(fc.sub_pixel_res * fc.sub_pixel_res);
+    const unsigned int si = sample % n2, pix = sample / n2;
+    const unsigned int col = pix % (unsigned int)fc.width, rowpos = pix / (unsigned int)fc.width;
+    // n == 1: the sample buffer is the frame (rowpos = image row); n > 1: band-local rows (one band = the frame's row range)
+    const int i = (n2 == 1) ? (int)rowpos - fc.first_row : (int)rowpos;
+    const unsigned long long r = (unsigned long long)(i % block_height), b = (unsigned long long)(i / block_height);
+    return ((r * (unsigned long long)nblocks + b) * (unsigned long long)fc.width + col) * n2 + si;
+}
+
+__global__ __launch_bounds__(256) void k_static_claim(FrameConst fc, const uint8_t* __restrict__ cache, const HitRec* __restrict__ hits,
+                                                      const unsigned int* __restrict__ count, unsigned long long* __restrict__ claim,
+                                                      int block_height, int nblocks) {
+    const unsigned int total = *count, stride = gridDim.x * 256u;
+    for (unsigned int h = blockIdx.x * 256u + threadIdx.x; h < total; h += stride) {
+        const uint32_t cell = static_cell(hits[h].pos);
+        if (cache[cell] == 0) atomicMin(&claim[cell], static_key(fc, hits[h].sample, block_height, nblocks));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_static_select(FrameConst fc, const uint8_t* __restrict__ cache, const HitRec* __restrict__ hits,
+                                                       const unsigned int* __restrict__ count, const unsigned long long* __restrict__ claim,
+                                                       int block_height, int nblocks, HitRec* __restrict__ gen, unsigned int* __restrict__ gen_count) {
+    const unsigned int total = *count, stride = gridDim.x * 256u;
+    for (unsigned int h = blockIdx.x * 256u + threadIdx.x; h < total; h += stride) {
+        HitRec r = hits[h];
+        const uint32_t cell = static_cell(r.pos);
+        if (cache[cell] == 0 && claim[cell] == static_key(fc, r.sample, block_height, nblocks)) {
+            r.pad[0] = cell;
+            gen[atomicAdd(gen_count, 1u)] = r;            // at most one winner per cell: <= 128^3 entries
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_static_apply(const uint8_t* __restrict__ cache, const HitRec* __restrict__ hits,
+                                                      const unsigned int* __restrict__ count, uint32_t* __restrict__ samples) {
+    const unsigned int total = *count, stride = gridDim.x * 256u;
+    for (unsigned int h = blockIdx.x * 256u + threadIdx.x; h < total; h += stride) {
+        const uint32_t sample = hits[h].sample;
+        samples[sample] = modulate(samples[sample], (uint32_t)cache[static_cell(hits[h].pos)]);   // ShadowMethod.cs:118
+    }
 }
 
 // --------------------------------------------------------------------------------------------------
@@ -1205,7 +1286,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         if (L.stats) hipLaunchKernelGGL((k_shadow_rays<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, L.fallback, fst, L.fallback_rays, L.fallback_ray_cap, ray_count, L.counters + 12, L.stats);
         else hipLaunchKernelGGL((k_shadow_rays<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, L.fallback, fst, L.fallback_rays, L.fallback_ray_cap, ray_count, L.counters + 12, L.stats);
         if ((e = hipGetLastError()) != hipSuccess) return e;
-        hipLaunchKernelGGL(k_fb_resolve, dim3(small), dim3(256), 0, L.stream, L.fc, (const HitRec*)L.hits, fb_count, L.fallback, (const RoundState*)fst, samples);
+        hipLaunchKernelGGL(k_fb_resolve, dim3(small), dim3(256), 0, L.stream, L.sc, L.fc, (const HitRec*)L.hits, fb_count, L.fallback, (const RoundState*)fst, samples);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         unsigned wblocks = (unsigned)std::min<long long>((max_hits + 3) / 4, (long long)L.persistent_blocks * 2);
         if (L.stats) hipLaunchKernelGGL((k_shadow_wave<EXTRA, true>), dim3(wblocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, ovf_count, L.fallback_overflow, L.fallback, (const RoundState*)fst, samples, L.stats);
@@ -1236,7 +1317,29 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
                                    : launch_primary_s<MODE, EXTRA, false>(L, row_begin, row_count, samples);
         if (e != hipSuccess) return e;
         if (e1) { e = hipEventRecord(e1, L.stream); if (e != hipSuccess) return e; }
-        if (shadows) {
+        if (shadows && (L.fc.flags & 32u)) {
+            // ---- static frame: claim cells, run the shadow kernels on the generators only, apply the cache ----
+            // counters: [0] hit points of the band  [13] generators  [14] copy of [0] while the generators are processed
+            const long long max_hits = (long long)row_count * L.fc.width * n2;
+            const int conc = L.static_concurrency > 0 ? L.static_concurrency : 4;        // Renderer.cs:92
+            const int block_height = (L.fc.num_rows - 1 + conc) / conc;                    // :1661
+            const int nblocks = (L.fc.num_rows - 1 + block_height) / block_height;
+            const unsigned blocks = (unsigned)std::min<long long>((max_hits + 255) / 256, (long long)L.persistent_blocks);
+            if ((e = hipMemsetAsync(L.static_claim, 0xff, (size_t)kStaticRes * kStaticRes * kStaticRes * 8, L.stream)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_static_claim, dim3(blocks), dim3(256), 0, L.stream, L.fc, (const uint8_t*)L.sc.shadow_cache, (const HitRec*)L.hits, L.counters,
+                               L.static_claim, block_height, nblocks);
+            hipLaunchKernelGGL(k_static_select, dim3(blocks), dim3(256), 0, L.stream, L.fc, (const uint8_t*)L.sc.shadow_cache, (const HitRec*)L.hits, L.counters,
+                               (const unsigned long long*)L.static_claim, block_height, nblocks, (HitRec*)L.static_hits, L.counters + 13);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = hipMemcpyAsync(L.counters + 14, L.counters, 4, hipMemcpyDeviceToDevice, L.stream)) != hipSuccess) return e;
+            if ((e = hipMemcpyAsync(L.counters, L.counters + 13, 4, hipMemcpyDeviceToDevice, L.stream)) != hipSuccess) return e;
+            PipelineLaunch G = L;
+            G.hits = L.static_hits;
+            e = launch_shadow_t<MODE, EXTRA>(G, samples, std::min<long long>(max_hits, (long long)kStaticRes * kStaticRes * kStaticRes));
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(k_static_apply, dim3(blocks), dim3(256), 0, L.stream, (const uint8_t*)L.sc.shadow_cache, (const HitRec*)L.hits, L.counters + 14, samples);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        } else if (shadows) {
             e = launch_shadow_t<MODE, EXTRA>(L, samples, (long long)row_count * L.fc.width * n2);
             if (e != hipSuccess) return e;
         }
@@ -1266,6 +1369,7 @@ hipError_t launch_pipeline(const PipelineLaunch& L) {
 }
 
 size_t pipeline_hit_record_bytes() { return sizeof(HitRec); }
+size_t pipeline_static_cells() { return (size_t)kStaticRes * kStaticRes * kStaticRes; }
 int pipeline_round_cap(int round) { return kRoundCap[round]; }   // default list length of a round
 size_t pipeline_round_state_bytes() { return sizeof(RoundState); }
 

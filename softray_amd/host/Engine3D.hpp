@@ -254,8 +254,8 @@ public:
     void Render() {                                        // Renderer.cs:701-778
         if (!rayTrace) throw std::logic_error("the scan-line rasteriser is out of scope of the MI355X hot path");
         if (!PinModel()) return;                           // silently, :736-739
-        if ((rayTraceShadows && rayTraceShadowsStatic) || rayTraceAmbientOcclusion || rayTraceLightField || rayTracePathTracing || rayTraceVoxels)
-            throw std::logic_error("static shadows / AO / light field / path tracing / voxels are out of scope (racy or RNG-order dependent in the reference)");
+        if (rayTraceAmbientOcclusion || rayTraceLightField || rayTracePathTracing || rayTraceVoxels)
+            throw std::logic_error("AO / light field / path tracing / voxels are out of scope (racy or RNG-order dependent in the reference)");
         for (auto& inst : Instances) {
             inst->FieldOfViewDepth = fieldOfViewDepth_;    // :749
             RaytraceGeometry(*inst);
@@ -275,11 +275,14 @@ public:
         f.start_row = rayTraceStartRow; f.end_row = rayTraceEndRow;
         f.sub_pixel_res = rayTraceSubPixelRes;
         f.background_argb = backgroundColor_;
-        f.flags = (rayTraceShading ? SR_F_SHADING : 0u) | (rayTraceShadows ? SR_F_SHADOWS : 0u) | (rayTraceFocalBlur ? SR_F_FOCAL_BLUR : 0u) |
+        f.flags = (rayTraceShading ? SR_F_SHADING : 0u) | (rayTraceShadows ? SR_F_SHADOWS : 0u) |
+                  (rayTraceShadows && rayTraceShadowsStatic ? SR_F_STATIC_SHADOWS : 0u) |      // Renderer.cs:1625; the cache lives in the scene
+                  (rayTraceFocalBlur ? SR_F_FOCAL_BLUR : 0u) |
                   (pointLighting ? SR_F_POINT_LIGHT : 0u) | (specularLighting ? SR_F_SPECULAR : 0u);
         f.random_seed = rayTraceRandomSeed;
         f.trace_mode = Mode();
         f.max_bounces = gpuMaxBounces;
+        f.concurrency = rayTraceConcurrency;              // fixes the fill order of the static shadow cache
         f.reflectivity = gpuReflectivity;
         double pos[3] = {instance.Position.x, instance.Position.y, instance.Position.z};
         sr_instance_matrices(pos, instance.Yaw, instance.Pitch, instance.Roll, f.transform, f.inv_transform);   // Instance.cs:134-135

@@ -14,7 +14,7 @@ import math
 import numpy as np
 
 from . import _lib
-from ._lib import (F_FOCAL_BLUR, F_POINT_LIGHT, F_SHADING, F_SHADOWS, F_SPECULAR, MODE_BRUTE, MODE_BVH,
+from ._lib import (F_FOCAL_BLUR, F_POINT_LIGHT, F_SHADING, F_SHADOWS, F_SPECULAR, F_STATIC_SHADOWS, MODE_BRUTE, MODE_BVH,
                    MODE_REF_TREE, Frame)
 from .scene import GpuScene, default_fov_depth, instance_matrices
 
@@ -363,8 +363,8 @@ class Renderer:
             raise NotImplementedError("the scan-line rasteriser is out of scope of the MI355X hot path (SURVEY.md 2, row 21)")
         if not self._PinModel():
             return                                                 # silently, Renderer.cs:736-739
-        for name in ("rayTraceShadowsStatic", "rayTraceAmbientOcclusion", "rayTraceLightField", "rayTracePathTracing", "rayTraceVoxels"):
-            if getattr(self, name) and (name != "rayTraceShadowsStatic" or self.rayTraceShadows):
+        for name in ("rayTraceAmbientOcclusion", "rayTraceLightField", "rayTracePathTracing", "rayTraceVoxels"):
+            if getattr(self, name):
                 raise NotImplementedError("%s is out of scope (RNG-order / racy-cache dependent in the reference; SURVEY.md 2)" % name)
         for instance in self.Instances:
             instance.FieldOfViewDepth = self._fieldOfViewDepth     # Renderer.cs:749
@@ -413,6 +413,8 @@ class Renderer:
             flags |= F_SHADING
         if self.rayTraceShadows:
             flags |= F_SHADOWS
+            if self.rayTraceShadowsStatic:
+                flags |= F_STATIC_SHADOWS                         # Renderer.cs:1625; cache lives in the GpuScene
         if self.rayTraceFocalBlur:
             flags |= F_FOCAL_BLUR
         if self.pointLighting:
@@ -438,6 +440,7 @@ class Renderer:
         for i, v in enumerate(self.positionalLight_pos):
             f.light_pos_view[i] = v
         f.max_bounces = self.gpuMaxBounces
+        f.concurrency = self.rayTraceConcurrency                 # fixes the static-shadow cache fill order
         f.reflectivity = self.gpuReflectivity
         f.area_light_offsets = None
         return f

@@ -116,6 +116,10 @@ class GpuScene:
         _check(_lib.lib().sr_anti_alias_device(self._h, C.c_void_p(d_src_ptr), int(dst_width), int(dst_height), int(resolution),
                                                C.c_void_p(d_dst_ptr), C.c_void_p(stream)))
 
+    def reset_shadow_cache(self):
+        """Forget the static shadow cache (SR_F_STATIC_SHADOWS): what a new Renderer starts with."""
+        _check(_lib.lib().sr_reset_shadow_cache(self._h))
+
     def ray_stats(self):
         """primary {rays, tests, nodes, leaves} + secondary {rays, tests, nodes, leaves} of the last render(stats=True)."""
         out = np.zeros(12, dtype=np.uint64)

@@ -48,7 +48,8 @@ static void RendererSetup(Renderer& renderer, const std::string& modelFileName, 
 }
 
 // RendererTests.RaytraceScenario (RendererTests.cs:381-459), in-scope flags only
-static int RaytraceScenario(const std::string& dir, bool shading, bool focalBlur, bool shadows, int subPixelRes, int resolution) {
+static int RaytraceScenario(const std::string& dir, bool shading, bool focalBlur, bool shadows, int subPixelRes, int resolution,
+                            bool staticShadows = false) {
     const double objectDepth = 1.0;
     Renderer renderer(0);
     RendererSetup(renderer, dir + "/obj.3ds", -22.0, 135.0, 0.0, objectDepth, resolution);
@@ -59,7 +60,8 @@ static int RaytraceScenario(const std::string& dir, bool shading, bool focalBlur
     renderer.rayTraceFocalDepth = objectDepth + 0.5;
     renderer.rayTraceSubPixelRes = subPixelRes;
     renderer.rayTraceShadows = shadows;
-    std::string name = std::string(shading ? "shading" : "noShading") + (shadows ? "_shadows" : "") + (focalBlur ? "_focalBlur" : "") +
+    renderer.rayTraceShadowsStatic = staticShadows;
+    std::string name = std::string(shading ? "shading" : "noShading") + (shadows ? (staticShadows ? "_staticShadows" : "_shadows") : "") + (focalBlur ? "_focalBlur" : "") +
                        (focalBlur ? "x" + std::to_string(subPixelRes) : (subPixelRes > 1 ? "_" + std::to_string(subPixelRes) + "xAA" : ""));
     std::string path = dir + "/raytrace/" + std::to_string(resolution) + "x" + std::to_string(resolution) + "/" + name + ".bmp";
     renderer.Render();
@@ -121,6 +123,8 @@ int main(int argc, char** argv) {
         bad += RaytraceScenario(dir, true, true, true, 4, 50);          // RaytraceShadowAndFocalBlur (:179-188)
         bad += RaytraceScenario(dir, true, false, true, 4, 50);         // RaytraceShadowAndAntiAlias (:207-213)
         bad += RaytraceScenario(dir, true, true, false, 2, 100);
+        bad += RaytraceScenario(dir, true, false, true, 1, 100, true);  // RaytraceStaticShadow (:167-175)
+        bad += RaytraceScenario(dir, false, false, true, 1, 100, true);
         bad += StyleAndAntiAliasScenario(dir);
         // error behaviour: Render() without a model draws nothing (Renderer.cs:736-739)
         { Renderer r(0); r.rayTrace = true; r.SetRenderingSurface(4, 4, pixels.data()); r.Render(); }

@@ -49,7 +49,8 @@ def renderer_default_light():
 def make_frame(res_w, res_h=None, shading=True, shadows=False, focal_blur=False, sub_pixel_res=1,
                yaw_deg=135.0, pitch_deg=-22.0, roll_deg=0.0, depth=1.0, focal_depth=None,
                background=0xff00ff, mode=orc.MODE_REF_TREE, point_light=True, specular=True,
-               shadow_samples=0, start_row=None, end_row=None, strips=None, position=None):
+               shadow_samples=0, start_row=None, end_row=None, strips=None, position=None, static_shadows=False,
+               concurrency=0):
     """The frame RendererTests.RaytraceScenario sets up (RendererTests.cs:65-90,381-417)."""
     if res_h is None:
         res_h = res_w
@@ -70,7 +71,10 @@ def make_frame(res_w, res_h=None, shading=True, shadows=False, focal_blur=False,
         flags |= orc.F_POINT_LIGHT
     if specular:
         flags |= orc.F_SPECULAR
+    if static_shadows:
+        flags |= orc.F_STATIC_SHADOWS                    # rayTraceShadowsStatic (with shadows=True)
     f.flags = flags
+    f.concurrency = concurrency                         # rayTraceConcurrency, 0 => the default 4
     f.random_seed = 1234567890
     f.shadow_samples = shadow_samples
     f.trace_mode = mode

@@ -27,7 +27,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(L, n), "libsoftray_hip.so does not export %s" % n
     assert sorted(sa._lib.SYMBOLS) == names
-    assert L.sr_abi_version() == 1
+    assert L.sr_abi_version() == 2              # sr_frame gained `concurrency` (static shadows)
 
 
 def test_frame_layout_matches_oracle_frame():

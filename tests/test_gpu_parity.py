@@ -438,3 +438,62 @@ def test_device_built_bvh_gives_identical_pixels():
     g.build((sa.MODE_BVH,), on_device=True)
     got, _ = g.render(as_sr(make_frame(100, shadows=True), sa.MODE_BVH))
     assert int(np.count_nonzero((got.reshape(100, 100) & 0xFFFFFF) != golden_rgb("shading_shadows", 100))) == 0
+
+
+def test_static_shadows_match_oracle_and_goldens(obj_pair):
+    """rayTraceShadowsStatic: the reference's two goldens (RendererTests.RaytraceStaticShadow), the oracle's
+    lock-step fill order on other poses / sub-pixel settings / concurrencies, the cache surviving a frame, reset, and the
+    combinations that have no defined fill order."""
+    g, o = obj_pair
+    for name, kw in (("shading_staticShadows", dict()), ("noShading_staticShadows", dict(shading=False))):
+        for mode in (sa.MODE_REF_TREE, sa.MODE_BVH):
+            g.reset_shadow_cache()
+            got, _ = g.render(as_sr(make_frame(100, shadows=True, static_shadows=True, **kw), mode))
+            assert int(np.count_nonzero((got.reshape(100, 100) & 0xFFFFFF) != golden_rgb(name, 100))) == 0, (name, mode)
+    for kw in (dict(concurrency=1), dict(concurrency=3), dict(sub_pixel_res=2), dict(sub_pixel_res=3, focal_blur=True),
+               dict(start_row=7, end_row=61), dict(shadow_samples=7)):
+        f = make_frame(80, 72, shadows=True, static_shadows=True, **kw)
+        o.reset_shadow_cache()
+        want, _ = o.render(f)
+        for mode in (sa.MODE_BVH, sa.MODE_REF_TREE, sa.MODE_BRUTE):
+            g.reset_shadow_cache()
+            got, _ = g.render(as_sr(f, mode))
+            assert np.array_equal(got, want), (kw, mode)
+    # the cache outlives the frame: B after A == the oracle's B after A, and differs from B on an empty cache
+    fa = make_frame(64, shadows=True, static_shadows=True)
+    fb = make_frame(64, shadows=True, static_shadows=True, yaw_deg=100.0)
+    o.reset_shadow_cache(); g.reset_shadow_cache()
+    o.render(fa); g.render(as_sr(fa, sa.MODE_BVH))
+    want_b, _ = o.render(fb)
+    got_b, _ = g.render(as_sr(fb, sa.MODE_BVH))
+    assert np.array_equal(got_b, want_b)
+    g.reset_shadow_cache()
+    fresh_b, _ = g.render(as_sr(fb, sa.MODE_BVH))
+    assert not np.array_equal(fresh_b, got_b)
+    # a dynamic-shadow frame does not touch the cache, and static without shadows is plain shading (RendererTests.cs:420)
+    dyn, _ = g.render(as_sr(make_frame(64, shadows=True), sa.MODE_BVH))
+    want_dyn, _ = o.render(make_frame(64, shadows=True), threads=NCPU)
+    assert np.array_equal(dyn, want_dyn)
+    ns, _ = g.render(as_sr(make_frame(64, static_shadows=True), sa.MODE_BVH))
+    assert np.array_equal(ns, o.render(make_frame(64), threads=NCPU)[0])
+    for bad in (dict(strips=(4, 2, 0)),):
+        with pytest.raises(sa.SoftrayError) as e:
+            g.render(as_sr(make_frame(32, shadows=True, static_shadows=True, **bad), sa.MODE_BVH))
+        assert e.value.code == sa._lib.SR_ERR_UNSUPPORTED
+    fsk = as_sr(make_frame(32, shadows=True, static_shadows=True), sa.MODE_BVH, single_kernel=True)
+    with pytest.raises(sa.SoftrayError):
+        g.render(fsk)
+
+
+def test_static_shadows_random_scene_and_extras():
+    v9, argb, bmin, bmax = unit_cube_scene(5000)
+    g = sa.GpuScene(0); o = orc.Scene()
+    for s in (g, o):
+        s.set_triangles(v9, argb, bmin, bmax)
+    g.build((sa.MODE_BVH,)); assert o.build_tree() == 0
+    prims = c1_spheres(6)
+    g.set_extra(prims); o.set_extra(prims)
+    f = make_frame(120, 96, depth=1.5, shadows=True, static_shadows=True)
+    want, _ = o.render(f)
+    got, _ = g.render(as_sr(f, sa.MODE_BVH))
+    assert np.array_equal(got, want)

@@ -263,3 +263,41 @@ def test_threads_do_not_change_result(obj_scene):
     a, sa = obj_scene.render(make_frame(48, shadows=True, sub_pixel_res=2), threads=1)
     b, sb = obj_scene.render(make_frame(48, shadows=True, sub_pixel_res=2), threads=5)
     assert np.array_equal(a, b) and np.array_equal(sa, sb)
+
+
+# ---------------------------------------------------------------- rayTraceShadowsStatic
+@pytest.mark.parametrize("name,kw", [("shading_staticShadows", dict()), ("noShading_staticShadows", dict(shading=False))])
+def test_static_shadow_goldens(name, kw):
+    """RendererTests.RaytraceStaticShadow (RendererTests.cs:167-175): the reference fills its 128^3 shadow cache from four
+    racing row-block tasks; the oracle's deterministic order (the blocks in lock step) reproduces both goldens exactly.
+    Plain scan order does not (9 pixels on the block seams differ), which is what pins the definition."""
+    v9, argb, bmin, bmax = load_obj3ds()
+    s = orc.Scene()
+    s.set_triangles(v9, argb, bmin, bmax)
+    assert s.build_tree() == 0
+    px, _ = s.render(make_frame(100, shadows=True, static_shadows=True, **kw))
+    assert int(np.count_nonzero((px.reshape(100, 100) & 0xFFFFFF) != golden_rgb(name, 100))) == 0
+    # one task = plain scan order: a different (also deterministic) fill order, different seam pixels
+    s.reset_shadow_cache()
+    px1, _ = s.render(make_frame(100, shadows=True, static_shadows=True, concurrency=1, **kw))
+    assert 0 < int(np.count_nonzero(px1 != px)) < 50
+
+
+def test_static_shadow_cache_outlives_the_frame():
+    """The cache belongs to the renderer (ShadowMethod is created once, Renderer.cs:1621-1628): a second frame reuses the
+    cells of the first, so rendering B after A differs from rendering B with an empty cache; reset = new Renderer."""
+    v9, argb, bmin, bmax = load_obj3ds()
+    s = orc.Scene()
+    s.set_triangles(v9, argb, bmin, bmax)
+    assert s.build_tree() == 0
+    fa = make_frame(64, shadows=True, static_shadows=True)
+    fb = make_frame(64, shadows=True, static_shadows=True, yaw_deg=100.0)
+    a1, _ = s.render(fa)
+    b_after_a, _ = s.render(fb)
+    a2, _ = s.render(fa)
+    assert np.array_equal(a1, a2)                       # every cell A needs is already there
+    s.reset_shadow_cache()
+    b_fresh, _ = s.render(fb)
+    assert not np.array_equal(b_after_a, b_fresh)
+    with pytest.raises(RuntimeError):                    # a frame split over ranks has no single fill order
+        s.render(make_frame(32, shadows=True, static_shadows=True, strips=(4, 2, 0)))
