@@ -45,6 +45,8 @@ def make_frame(args, strips=None):
     flags = sa.F_POINT_LIGHT | sa.F_SPECULAR | sa.F_SHADING
     if args.shadows > 0:
         flags |= sa.F_SHADOWS
+        if getattr(args, "static_shadows", False):
+            flags |= sa.F_STATIC_SHADOWS                              # rayTraceShadowsStatic: 128^3 cache, kept by the scene
     f.flags = flags
     f.random_seed = 1234567890
     f.shadow_samples = args.shadows if args.shadows > 0 else 0
@@ -125,6 +127,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1, help="rayTraceSubPixelRes")
     ap.add_argument("--mode", default="bvh", choices=["bvh", "ref", "brute"])
     ap.add_argument("--depth", type=float, default=1.5)
+    ap.add_argument("--static-shadows", action="store_true", help="rayTraceShadowsStatic (cache reset before every step: cold cache)")
     ap.add_argument("--bounces", type=int, default=0, help="config-5 extension: mirror bounces (unpinned; one-kernel renderer)")
     ap.add_argument("--reflectivity", type=float, default=0.5)
     ap.add_argument("--extent", type=float, default=0.05, help="triangle extent of the synthetic soup (SURVEY 8d: 0.05 at 1M, 0.02 at 10M)")
@@ -172,6 +175,8 @@ def main():
         assert sg.counts[rank] == npix
 
     def step():
+        if args.static_shadows:
+            g.reset_shadow_cache()                                   # every step generates the whole cache again
         g.render_device(frame, local.data_ptr(), stream.cuda_stream)
         if sg:
             sg.exchange()                                             # RCCL gather over xGMI + de-interleave on rank 0
