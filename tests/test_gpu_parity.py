@@ -377,6 +377,18 @@ def test_full_size_properties():
     fo = make_frame(4096, depth=1.5, shadows=True, start_row=2047, end_row=2048)
     want, _ = o.render(fo, threads=NCPU)
     assert np.array_equal(want.reshape(4096, 4096)[2047:2049], a2[2047:2049])
+    # (d) static shadow cache at 4096^2: a warm cache reproduces the frame (every cell it needs exists), shadow-less pixels are
+    #     untouched, and every shadowed pixel is its shaded colour modulated by SOME cache byte 1..255
+    fs = make_frame(4096, depth=1.5, shadows=True, static_shadows=True)
+    g.reset_shadow_cache()
+    s1, _ = g.render(as_sr(fs, sa.MODE_BVH))
+    s2, _ = g.render(as_sr(fs, sa.MODE_BVH))
+    assert np.array_equal(s1, s2)
+    plain, _ = g.render(as_sr(make_frame(4096, depth=1.5), sa.MODE_BVH))
+    bg = plain == 0xFFFF00FF
+    assert np.array_equal(s1[bg], plain[bg]) and bg.sum() > 100000
+    assert np.all(((s1 >> 16) & 255) <= ((plain >> 16) & 255)) and np.all((s1 & 255) <= (plain & 255))
+    assert np.count_nonzero(s1 != plain) > 1000000
 
 
 def test_reflection_extension_matches_oracle():
