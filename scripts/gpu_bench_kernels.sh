@@ -1,4 +1,4 @@
-# timing-only experiments selected by SR_DEBUG (images are wrong in these modes)
+# default bench with the per-kernel table printed; arguments are SR_DEBUG values (0 = production; 7 counts umbra hits)
 cd ${GRAFT_REPO_ROOT:-/root/repo}
 for m in "$@"; do
   SR_DEBUG=$m python bench.py --no-cpu-baseline > gpurun_out/bench_dbg_$m.json 2> gpurun_out/bench_dbg_$m.err

@@ -269,7 +269,7 @@ struct BvhBuilder {
     Bvh& out;
     const RootBox& root;
     double pad;
-    int kLeafMax = 4;                // triangles per leaf (SR_BVH_LEAF = 1..4 overrides: experiment hook)
+    int kLeafMax = 4;                // triangles per leaf (SR_BVH_LEAF = 1..7 overrides: experiment hook, scripts/gpu_leaf.sh)
 
     float down(double v) const { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; }
     float up(double v) const { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; }
