@@ -33,8 +33,13 @@ class StripGather:
         self.gather_list = None
         if rank == 0:
             self.full = torch.zeros((height, width), dtype=torch.int32, device=device)
-            self.gather_list = [torch.empty(max(1, self.maxc), dtype=torch.int32, device=device) for _ in range(world)]
+            # one receive buffer, one row per rank: when every rank owns the same number of rows (the usual case) the
+            # de-interleave is a single indexed copy instead of one per rank
+            self.gbuf = torch.empty((world, max(1, self.maxc)), dtype=torch.int32, device=device)
+            self.gather_list = [self.gbuf[k] for k in range(world)]
             self.row_idx = [torch.tensor(r, dtype=torch.long, device=device) for r in self.rows]
+            self.uniform = self.maxc > 0 and all(c == self.maxc for c in self.counts)
+            self.rows_all = torch.cat(self.row_idx) if self.uniform else None
 
     def exchange(self):
         """dist.gather (RCCL send/recv over xGMI on GPUs, gloo on CPU) + de-interleave on rank 0."""
@@ -44,7 +49,10 @@ class StripGather:
             return self.full
         dist.gather(self.local, self.gather_list, dst=0)
         if self.rank == 0:
-            for k in range(self.world):
-                if self.counts[k]:
-                    self.full[self.row_idx[k]] = self.gather_list[k][: self.counts[k]].view(-1, self.width)
+            if self.uniform:
+                self.full[self.rows_all] = self.gbuf.view(-1, self.width)
+            else:
+                for k in range(self.world):
+                    if self.counts[k]:
+                        self.full[self.row_idx[k]] = self.gather_list[k][: self.counts[k]].view(-1, self.width)
         return self.full
