@@ -70,6 +70,8 @@ def make_frame(args, strips=None):
         f.light_dir_view[i] = v
     for i, v in enumerate(lp):
         f.light_pos_view[i] = v
+    if getattr(args, "no_split", False):
+        f.flags |= sa._lib.F_NO_SPLIT                                # one pipeline on the caller's stream (kernel timing)
     if args.bounces > 0:
         f.max_bounces, f.reflectivity = args.bounces, args.reflectivity
     if args.shadows == 1:                                            # hard-shadow variant: one sample, zero offset
@@ -127,6 +129,7 @@ def main():
     ap.add_argument("--spp", type=int, default=1, help="rayTraceSubPixelRes")
     ap.add_argument("--mode", default="bvh", choices=["bvh", "ref", "brute"])
     ap.add_argument("--depth", type=float, default=1.5)
+    ap.add_argument("--no-split", action="store_true", help="SR_F_NO_SPLIT for every frame: one pipeline, no overlapping kernels")
     ap.add_argument("--static-shadows", action="store_true", help="rayTraceShadowsStatic (cache reset before every step: cold cache)")
     ap.add_argument("--bounces", type=int, default=0, help="config-5 extension: mirror bounces (unpinned; one-kernel renderer)")
     ap.add_argument("--reflectivity", type=float, default=0.5)
@@ -199,8 +202,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # per-kernel device time over the K timed steps: one HIP event pair per launch on the launch stream,
-    # recorded inside the library; average = total / launches
+    # per-kernel device time: one HIP event pair per launch on the launch stream, recorded inside the library; average =
+    # total / launches.  The timed steps above run the frame as two concurrent halves (two internal streams), so their
+    # kernels share the GPU pairwise; the durations the roofline uses come from K more frames rendered as ONE pipeline
+    # (SR_F_NO_SPLIT: same kernels, same work per frame, no overlap), timed as a whole for reference
+    frame_ns = sa.Frame.from_buffer_copy(bytes(frame))
+    frame_ns.flags |= sa._lib.F_NO_SPLIT
+    if frame.area_light_offsets:
+        frame_ns.area_light_offsets = frame.area_light_offsets
+    g.render_device(frame_ns, local.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    g.reset_kernel_times()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        g.render_device(frame_ns, local.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    ms_unsplit = (time.perf_counter() - t1) / args.steps * 1e3
     kt = {k: (ms / max(1, n), n) for k, (ms, n) in g.kernel_times().items()}
 
     primary_rays = args.res * args.res * args.spp * args.spp
@@ -282,10 +299,12 @@ def main():
                          "all_kernels_algorithmic_GBs": {k: algo.get(k, 0.0) / (v * 1e-3) / 1e9 for k, v in fam_ms.items() if v > 0},
                          "per_ray_touch_bytes_per_frame": per_ray_touch, "issue_bound": issue,
                          "note": "achieved = wave-granular algorithmic bytes of the dominant kernel family per frame / its device time per frame "
-                                 "(HIP event pairs around every launch).  The scene (128 MB records + 21 MB BVH + 64 MB slabs) is cache "
+                                 "(HIP event pairs around every launch of K frames rendered as one pipeline, SR_F_NO_SPLIT, so that no two kernels share "
+                                 "the GPU; `value` is measured with the default two concurrent half-frame pipelines).  The scene (128 MB records + 21 MB BVH + 64 MB slabs) is cache "
                                  "resident and the kernels are FP64-issue / latency bound, not HBM bound; per_ray_touch is SURVEY 8d's "
                                  "per-lane figure (4 B + 64 B/node + 128 B/triangle test per ray)"},
             "kernels_ms": {k: v[0] for k, v in kt.items()}, "kernel_launches": {k: v[1] for k, v in kt.items()},
+            "ms_per_step_one_pipeline": ms_unsplit,
             "pipeline_counters_last_band": g.debug_counters(), "device_counters": [float(x) for x in rs],
             "build_s": build_s, "d2h_ms": d2h_ms,
         }

@@ -67,6 +67,10 @@ enum {
     SR_F_SINGLE_KERNEL = 1u << 8, /* library option, not a Renderer field: trace the frame with the one-kernel
                                      renderer (k_render) instead of the k_primary/k_shadow/k_resolve pipeline.
                                      Pixels are identical; kept as an independent cross-check               */
+    SR_F_NO_SPLIT    = 1u << 10,  /* library option: run the frame as ONE pipeline on the caller's stream instead of two
+                                     halves on two internal streams (the default: the latency-bound tail kernels of one
+                                     half overlap the other half's work, -5 % frame time).  Same pixels; used to time
+                                     kernels that do not share the GPU with another kernel                       */
     SR_F_PER_LANE_SHADOWS = 1u << 9 /* library option: trace shadow samples one lane per hit point (k_shadow)
                                      instead of one wavefront per hit point with a shared shaft walk
                                      (k_shadow_packet).  Pixels are identical; cross-check                  */

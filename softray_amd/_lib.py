@@ -17,6 +17,7 @@ SR_ERR_UNSUPPORTED, SR_ERR_NO_DEVICE, SR_ERR_HIP, SR_ERR_FORMAT = -5, -6, -7, -8
 F_SHADING, F_SHADOWS, F_FOCAL_BLUR, F_POINT_LIGHT, F_SPECULAR, F_STATIC_SHADOWS = 1, 2, 4, 8, 16, 32
 F_SINGLE_KERNEL = 1 << 8
 F_PER_LANE_SHADOWS = 1 << 9
+F_NO_SPLIT = 1 << 10
 MODE_REF_TREE, MODE_BRUTE, MODE_BVH = 0, 1, 2
 TARGET_ROOT = 0x100
 BUILD_ON_DEVICE = 0x100

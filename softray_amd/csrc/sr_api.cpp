@@ -76,7 +76,25 @@ struct sr_scene {
     DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab;
     DBuf d_shadow_cache, d_static_claim, d_static_hits;
     bool shadow_cache_empty = true;      // the device cache must be zeroed before its next use
-    DBuf d_offsets, d_rowmap, d_pixels, d_aa, d_stats, d_io[9], d_hits, d_samples, d_counters, d_fallback, d_fallback_state, d_fallback_rays, d_fallback_ovf, d_rlist[sr::kShaftRounds], d_rstate[sr::kShaftRounds], d_rcount[sr::kShaftRounds], d_rcand[sr::kShaftRounds];
+    DBuf d_offsets, d_rowmap, d_pixels, d_aa, d_stats, d_io[9];
+    // per-band scratch of the pipeline.  Two sets + two internal streams: the two halves of a frame run concurrently, so that
+    // the short, latency-bound tail kernels of one half (second shaft round, fallback walks) overlap the other half's work
+    static constexpr int kMaxSplit = 4;
+    struct BandScratch {
+        DBuf hits, samples, counters, fallback, fallback_state, fallback_rays, fallback_ovf;
+        DBuf rlist[sr::kShaftRounds], rstate[sr::kShaftRounds], rcount[sr::kShaftRounds], rcand[sr::kShaftRounds];
+        hipStream_t stream = nullptr;
+        hipEvent_t  done = nullptr;
+        void release() {
+            DBuf* b[] = {&hits, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf};
+            for (DBuf* x : b) x->release();
+            for (int r = 0; r < sr::kShaftRounds; ++r) { rlist[r].release(); rstate[r].release(); rcount[r].release(); rcand[r].release(); }
+            if (stream) (void)hipStreamDestroy(stream);
+            if (done) (void)hipEventDestroy(done);
+            stream = nullptr; done = nullptr;
+        }
+    } scratch[kMaxSplit];
+    hipEvent_t fork = nullptr;
     int num_cus = 0;
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
     std::vector<double>  offsets_host;
@@ -291,79 +309,108 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         if (const char* e = std::getenv("SR_ROUND_CAP0")) round_cap[0] = std::min(std::max(1, std::atoi(e)), sr::pipeline_round_cap(0));
         if (const char* e = std::getenv("SR_ROUND_CAP1")) round_cap[1] = std::min(std::max(1, std::atoi(e)), sr::pipeline_round_cap(1));
     }
-    long long band_rows = std::max<long long>(16, (kMaxBandSamples / ((long long)fc.width * n2)) / 16 * 16);
-    band_rows = std::min<long long>(band_rows, ((long long)fc.num_rows + 15) / 16 * 16);
+    // Two halves of the frame (16-row granularity) run as two pipelines on two internal streams, each with its own scratch
+    // set; a half that exceeds its share of the band budget is processed in sequential bands on its stream.  A static
+    // frame (one global fill order) and shadow-less frames (one kernel) stay whole on the first set.
+    int want_split = 2;
+    if (const char* e = std::getenv("SR_SPLIT")) want_split = std::min(std::max(1, std::atoi(e)), (int)sr_scene::kMaxSplit);   // experiment hook
+    const bool split = shadows && !static_shadows && want_split > 1 && fc.num_rows >= 32 * want_split && !(f->flags & SR_F_NO_SPLIT);
+    const int halves = split ? want_split : 1;
+    const int rows_half = split ? (int)((((long long)fc.num_rows + halves - 1) / halves + 15) / 16 * 16) : fc.num_rows;
+    const long long budget = kMaxBandSamples / halves;
+    long long band_rows = std::max<long long>(16, (budget / ((long long)fc.width * n2)) / 16 * 16);
+    band_rows = std::min<long long>(band_rows, ((long long)rows_half + 15) / 16 * 16);
     const long long band_samples = band_rows * fc.width * n2;
-    if (shadows) SR_HIP(s->d_hits.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
     if (static_shadows) {
         if (band_rows < fc.num_rows) return fail(SR_ERR_UNSUPPORTED, "static shadows: the frame does not fit one row band");
         SR_HIP(s->d_static_hits.reserve((size_t)std::min<long long>(band_samples, (long long)sr::pipeline_static_cells()) * sr::pipeline_hit_record_bytes()));
     }
     // fallback ray list: one 32-bit id (entry << 7 | sample; bands have < 2^25 entries) per undecided sample.  6 per band
-    // sample = 0.4 GB for a 4096^2 band; whatever it has no room for is taken by the one-wave-per-hit kernel.  Test hook
+    // sample = 0.4 GB for a 4096^2 frame; whatever it has no room for is taken by the one-wave-per-hit kernel.  Test hook
     // SR_FB_RAY_CAP shrinks it
     long long fallback_ray_cap = std::min<long long>(6 * band_samples, 0xfffffff0ll);
     if (const char* e = std::getenv("SR_FB_RAY_CAP")) fallback_ray_cap = std::max(1ll, std::atoll(e));
     unsigned round_items[sr::kShaftRounds] = {};
-    if (shaft) {
-        SR_HIP(s->d_fallback.reserve((size_t)band_samples * 4));
-        SR_HIP(s->d_fallback_state.reserve((size_t)band_samples * sr::pipeline_round_state_bytes()));
-        SR_HIP(s->d_fallback_rays.reserve((size_t)fallback_ray_cap * 4));
-        SR_HIP(s->d_fallback_ovf.reserve((size_t)band_samples * 4));
-        for (int r = 0; r < sr::kShaftRounds; ++r) {
-            // round 0 sees every hit; each later round is provisioned for 1/8 of the previous one
-            round_items[r] = r == 0 ? (unsigned)band_samples : (unsigned)std::max<long long>(1024, (long long)round_items[r - 1] / 4);
-            SR_HIP(s->d_rcount[r].reserve((size_t)round_items[r] * 4));
-            SR_HIP(s->d_rcand[r].reserve((size_t)round_items[r] * sr::pipeline_round_cap(r) * 4));
-            SR_HIP(s->d_rlist[r].reserve((size_t)round_items[r] * 4));     // round 0: the hits k_shaft left undecided
-            if (r > 0) SR_HIP(s->d_rstate[r].reserve((size_t)round_items[r] * sr::pipeline_round_state_bytes()));
-        }
-    }
-    if (n2 > 1) SR_HIP(s->d_samples.reserve((size_t)band_samples * 4));
-    SR_HIP(s->d_counters.reserve(64));
+    for (int r = 0; r < sr::kShaftRounds; ++r)      // round 0 sees every hit; each later round is provisioned for 1/4 of the previous one
+        round_items[r] = r == 0 ? (unsigned)band_samples : (unsigned)std::max<long long>(1024, (long long)round_items[r - 1] / 4);
     if (!s->num_cus) {
         hipDeviceProp_t prop;
         SR_HIP(hipGetDeviceProperties(&prop, s->device));
         s->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    sr::PipelineLaunch P{};
-    P.sc = dev_scene(s);
-    P.fc = fc;
-    P.mode = f->trace_mode;
-    P.offsets = (const double*)s->d_offsets.p;
-    P.row_map = (const int32_t*)s->d_rowmap.p;
-    P.pixels = d_pixels;
-    P.samples = (uint32_t*)s->d_samples.p;
-    P.hits = s->d_hits.p;
-    P.counters = (unsigned int*)s->d_counters.p;
-    P.static_hits = static_shadows ? s->d_static_hits.p : nullptr;
-    P.static_claim = static_shadows ? (unsigned long long*)s->d_static_claim.p : nullptr;
-    P.static_concurrency = f->concurrency;
-    P.fallback = shaft ? (unsigned int*)s->d_fallback.p : nullptr;
-    P.fallback_state = shaft ? s->d_fallback_state.p : nullptr;
-    P.fallback_rays = shaft ? (unsigned int*)s->d_fallback_rays.p : nullptr;
-    P.fallback_ray_cap = (unsigned int)fallback_ray_cap;
-    P.fallback_overflow = shaft ? (unsigned int*)s->d_fallback_ovf.p : nullptr;
-    for (int r = 0; r < sr::kShaftRounds; ++r) {
-        P.round_items[r] = round_items[r];
-        P.round_cap[r] = round_cap[r];
-        P.round_list[r] = shaft ? (unsigned int*)s->d_rlist[r].p : nullptr;
-        P.round_state[r] = (shaft && r > 0) ? s->d_rstate[r].p : nullptr;
-        P.round_cand_count[r] = shaft ? (unsigned int*)s->d_rcount[r].p : nullptr;
-        P.round_cand[r] = shaft ? (int32_t*)s->d_rcand[r].p : nullptr;
+    if (split) {
+        if (!s->fork) SR_HIP(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
+        SR_HIP(hipEventRecord(s->fork, stream));                    // the halves start after the caller's earlier work
     }
-    P.band_rows = (int32_t)band_rows;
-    P.persistent_blocks = s->num_cus * 8;
-    P.per_lane_shadows = (f->flags & SR_F_PER_LANE_SHADOWS) != 0;
-    P.stats = d_stats;
-    P.stream = stream;
-    P.user = s;
-    P.get_events = [](void* user, int kid, hipEvent_t* a, hipEvent_t* b) {
-        hipEvent_t x = nullptr, y = nullptr;
-        if (next_events((sr_scene*)user, kid, x, y) != SR_OK) { x = y = nullptr; }
-        *a = x; *b = y;
-    };
-    SR_HIP(sr::launch_pipeline(P));
+    for (int h = 0; h < halves; ++h) {
+        sr_scene::BandScratch& B = s->scratch[h];
+        if (shadows) SR_HIP(B.hits.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
+        if (shaft) {
+            SR_HIP(B.fallback.reserve((size_t)band_samples * 4));
+            SR_HIP(B.fallback_state.reserve((size_t)band_samples * sr::pipeline_round_state_bytes()));
+            SR_HIP(B.fallback_rays.reserve((size_t)fallback_ray_cap * 4));
+            SR_HIP(B.fallback_ovf.reserve((size_t)band_samples * 4));
+            for (int r = 0; r < sr::kShaftRounds; ++r) {
+                SR_HIP(B.rcount[r].reserve((size_t)round_items[r] * 4));
+                SR_HIP(B.rcand[r].reserve((size_t)round_items[r] * sr::pipeline_round_cap(r) * 4));
+                SR_HIP(B.rlist[r].reserve((size_t)round_items[r] * 4));     // round 0: the hits k_shaft left undecided
+                if (r > 0) SR_HIP(B.rstate[r].reserve((size_t)round_items[r] * sr::pipeline_round_state_bytes()));
+            }
+        }
+        if (n2 > 1) SR_HIP(B.samples.reserve((size_t)band_samples * 4));
+        SR_HIP(B.counters.reserve(64));
+        hipStream_t bs = stream;
+        if (split) {
+            if (!B.stream) SR_HIP(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+            if (!B.done) SR_HIP(hipEventCreateWithFlags(&B.done, hipEventDisableTiming));
+            bs = B.stream;
+            SR_HIP(hipStreamWaitEvent(bs, s->fork, 0));
+        }
+        sr::PipelineLaunch P{};
+        P.sc = dev_scene(s);
+        P.fc = fc;
+        P.mode = f->trace_mode;
+        P.offsets = (const double*)s->d_offsets.p;
+        P.row_map = (const int32_t*)s->d_rowmap.p;
+        P.pixels = d_pixels;
+        P.samples = (uint32_t*)B.samples.p;
+        P.hits = B.hits.p;
+        P.counters = (unsigned int*)B.counters.p;
+        P.static_hits = static_shadows ? s->d_static_hits.p : nullptr;
+        P.static_claim = static_shadows ? (unsigned long long*)s->d_static_claim.p : nullptr;
+        P.static_concurrency = f->concurrency;
+        P.fallback = shaft ? (unsigned int*)B.fallback.p : nullptr;
+        P.fallback_state = shaft ? B.fallback_state.p : nullptr;
+        P.fallback_rays = shaft ? (unsigned int*)B.fallback_rays.p : nullptr;
+        P.fallback_ray_cap = (unsigned int)fallback_ray_cap;
+        P.fallback_overflow = shaft ? (unsigned int*)B.fallback_ovf.p : nullptr;
+        for (int r = 0; r < sr::kShaftRounds; ++r) {
+            P.round_items[r] = round_items[r];
+            P.round_cap[r] = round_cap[r];
+            P.round_list[r] = shaft ? (unsigned int*)B.rlist[r].p : nullptr;
+            P.round_state[r] = (shaft && r > 0) ? B.rstate[r].p : nullptr;
+            P.round_cand_count[r] = shaft ? (unsigned int*)B.rcount[r].p : nullptr;
+            P.round_cand[r] = shaft ? (int32_t*)B.rcand[r].p : nullptr;
+        }
+        P.band_rows = (int32_t)band_rows;
+        P.row_first = h * rows_half;
+        P.row_limit = std::min(fc.num_rows, (h + 1) * rows_half);
+        P.persistent_blocks = s->num_cus * 8;
+        P.per_lane_shadows = (f->flags & SR_F_PER_LANE_SHADOWS) != 0;
+        P.stats = d_stats;
+        P.stream = bs;
+        P.user = s;
+        P.get_events = [](void* user, int kid, hipEvent_t* a, hipEvent_t* b) {
+            hipEvent_t x = nullptr, y = nullptr;
+            if (next_events((sr_scene*)user, kid, x, y) != SR_OK) { x = y = nullptr; }
+            *a = x; *b = y;
+        };
+        if (P.row_first < P.row_limit) SR_HIP(sr::launch_pipeline(P));
+        if (split) {
+            SR_HIP(hipEventRecord(B.done, bs));
+            SR_HIP(hipStreamWaitEvent(stream, B.done, 0));          // the caller's stream continues after both halves
+        }
+    }
     return SR_OK;
 }
 
@@ -396,9 +443,10 @@ void sr_destroy(sr_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
-                        &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats, &s->d_hits, &s->d_samples, &s->d_counters, &s->d_fallback, &s->d_fallback_state, &s->d_fallback_rays, &s->d_fallback_ovf};
+                        &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats};
         for (DBuf* b : bufs) b->release();
-        for (int r = 0; r < sr::kShaftRounds; ++r) { s->d_rlist[r].release(); s->d_rstate[r].release(); s->d_rcount[r].release(); s->d_rcand[r].release(); }
+        for (auto& sc : s->scratch) sc.release();
+        if (s->fork) (void)hipEventDestroy(s->fork);
         for (DBuf& b : s->d_io) b.release();
         for (int k = 0; k < sr::K_COUNT; ++k)
             for (hipEvent_t e : s->ev[k]) (void)hipEventDestroy(e);
@@ -719,9 +767,9 @@ int sr_debug_counters(sr_scene* s, uint32_t out[8]) {
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
     int rc = use_device(s);
     if (rc) return rc;
-    if (!s->d_counters.p) { for (int i = 0; i < 8; ++i) out[i] = 0; return SR_OK; }
+    if (!s->scratch[0].counters.p) { for (int i = 0; i < 8; ++i) out[i] = 0; return SR_OK; }
     SR_HIP(hipDeviceSynchronize());
-    SR_HIP(hipMemcpy(out, s->d_counters.p, 32, hipMemcpyDeviceToHost));
+    SR_HIP(hipMemcpy(out, s->scratch[0].counters.p, 32, hipMemcpyDeviceToHost));   // first half of the frame
     return SR_OK;
 }
 

@@ -73,6 +73,7 @@ struct PipelineLaunch {
     unsigned int  fallback_ray_cap;
     unsigned int* fallback_overflow; // device [band samples]: entries the ray list had no room for
     int32_t     band_rows;      // rows per band (multiple of 16)
+    int32_t     row_first, row_limit; // compact rows [row_first, row_limit) of the frame are this launch's share
     int32_t     persistent_blocks;
     bool        per_lane_shadows; // force k_shadow (one lane per hit) instead of k_shadow_packet (cross-check)
     unsigned long long* stats;  // device [8] or nullptr

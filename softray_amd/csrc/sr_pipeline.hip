@@ -1302,8 +1302,8 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
     const int n2 = L.fc.sub_pixel_res * L.fc.sub_pixel_res;
     const bool shadows = (L.fc.flags & 2u) != 0;
     // rows are processed in bands so that the hit queue / sample buffer stay within their allocation
-    for (int row_begin = 0; row_begin < L.fc.num_rows; row_begin += L.band_rows) {
-        int row_count = std::min(L.band_rows, L.fc.num_rows - row_begin);
+    for (int row_begin = L.row_first; row_begin < L.row_limit; row_begin += L.band_rows) {
+        int row_count = std::min(L.band_rows, L.row_limit - row_begin);
         uint32_t* samples = (n2 == 1) ? L.pixels : L.samples;
         hipError_t e;
         if (shadows) {

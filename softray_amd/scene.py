@@ -32,7 +32,10 @@ class GpuScene:
 
     def close(self):
         if getattr(self, "_h", None):
-            _lib.lib().sr_destroy(self._h)
+            try:
+                _lib.lib().sr_destroy(self._h)
+            except TypeError:                     # interpreter shutdown: the module globals are already gone
+                pass
             self._h = None
 
     __del__ = close
