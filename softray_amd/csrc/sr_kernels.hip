@@ -106,19 +106,9 @@ __global__ __launch_bounds__(256) void k_render(DevScene sc, FrameConst fc, cons
     }
     if (STATS) {
         uint32_t a = wave_sum(nrays), b = wave_sum(prim.geom), c2 = wave_sum(prim.nodes), d2 = wave_sum(prim.leaves);
-        if (lane == 0) {
-            atomicAdd(&stats[0], (unsigned long long)a);
-            atomicAdd(&stats[1], (unsigned long long)b);
-            atomicAdd(&stats[2], (unsigned long long)c2);
-            atomicAdd(&stats[3], (unsigned long long)d2);
-        }
+        block_stat_add(&stats[0], &stats[1], &stats[2], &stats[3], a, b, c2, d2);
         a = wave_sum(sec.rays); b = wave_sum(sec.geom); c2 = wave_sum(sec.nodes); d2 = wave_sum(sec.leaves);
-        if (lane == 0) {
-            atomicAdd(&stats[4], (unsigned long long)a);
-            atomicAdd(&stats[5], (unsigned long long)b);
-            atomicAdd(&stats[6], (unsigned long long)c2);
-            atomicAdd(&stats[7], (unsigned long long)d2);
-        }
+        block_stat_add(&stats[4], &stats[5], &stats[6], &stats[7], a, b, c2, d2);
     }
 }
 

@@ -139,12 +139,7 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
     }
     if (STATS) {
         uint32_t a = wave_sum(prim.rays), b = wave_sum(prim.geom), c2 = wave_sum(prim.nodes), d2 = wave_sum(prim.leaves);
-        if (lane == 0) {
-            atomicAdd(&stats[0], (unsigned long long)a);
-            atomicAdd(&stats[1], (unsigned long long)b);
-            atomicAdd(&stats[2], (unsigned long long)c2);
-            atomicAdd(&stats[3], (unsigned long long)d2);
-        }
+        block_stat_add(&stats[0], &stats[1], &stats[2], &stats[3], a, b, c2, d2);
     }
 }
 
@@ -254,10 +249,10 @@ __global__ __launch_bounds__(256) void k_shadow(DevScene sc, FrameConst fc, cons
     if (STATS) {
         uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom), c2 = wave_sum(sec.nodes), d2 = wave_sum(sec.leaves);
         if (lane == 0) {
-            atomicAdd(&stats[4], (unsigned long long)a);
-            atomicAdd(&stats[5], (unsigned long long)b);
-            atomicAdd(&stats[6], (unsigned long long)c2);
-            atomicAdd(&stats[7], (unsigned long long)d2);
+            stat_add(&stats[4], a);
+            stat_add(&stats[5], b);
+            stat_add(&stats[6], c2);
+            stat_add(&stats[7], d2);
         }
     }
 }
@@ -549,10 +544,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
     }
     if (STATS) {
         uint32_t a = wave_sum(nodes), b = wave_sum(leaves), c2 = wave_sum(slabs), d2 = wave_sum(slot_i < total ? 1u : 0u);
-        if (lane == 0) {
-            atomicAdd(&stats[6], (unsigned long long)a); atomicAdd(&stats[7], (unsigned long long)b);
-            atomicAdd(&stats[10], (unsigned long long)c2); atomicAdd(&stats[11], (unsigned long long)d2);
-        }
+        block_stat_add(&stats[6], &stats[7], &stats[10], &stats[11], a, b, c2, d2);
     }
 }
 
@@ -837,9 +829,9 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
     if (STATS) {
         uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom);
         if (lane == 0) {
-            atomicAdd(&stats[4], (unsigned long long)a); atomicAdd(&stats[5], (unsigned long long)b);
-            atomicAdd(&stats[8], (unsigned long long)sec.nodes);          // wave-level: records staged through LDS
-            atomicAdd(&stats[9], (unsigned long long)sec.leaves);         // wave-level: hit points processed
+            stat_add(&stats[4], a); stat_add(&stats[5], b);
+            stat_add(&stats[8], sec.nodes);          // wave-level: records staged through LDS
+            stat_add(&stats[9], sec.leaves);         // wave-level: hit points processed
         }
     }
 }
@@ -1010,8 +1002,8 @@ __global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc,
     if (STATS) {
         uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom), c2 = wave_sum(sec.nodes), d2 = wave_sum(sec.leaves);
         if (lane == 0) {
-            atomicAdd(&stats[4], (unsigned long long)a); atomicAdd(&stats[5], (unsigned long long)b);
-            atomicAdd(&stats[6], (unsigned long long)c2); atomicAdd(&stats[7], (unsigned long long)d2);
+            stat_add(&stats[4], a); stat_add(&stats[5], b);
+            stat_add(&stats[6], c2); stat_add(&stats[7], d2);
         }
     }
 }
@@ -1071,8 +1063,8 @@ __global__ __launch_bounds__(256) void k_shadow_wave(DevScene sc, FrameConst fc,
     if (STATS) {
         uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom), c2 = wave_sum(sec.nodes), d2 = wave_sum(sec.leaves);
         if (lane == 0) {
-            atomicAdd(&stats[4], (unsigned long long)a); atomicAdd(&stats[5], (unsigned long long)b);
-            atomicAdd(&stats[6], (unsigned long long)c2); atomicAdd(&stats[7], (unsigned long long)d2);
+            stat_add(&stats[4], a); stat_add(&stats[5], b);
+            stat_add(&stats[6], c2); stat_add(&stats[7], d2);
         }
     }
 }

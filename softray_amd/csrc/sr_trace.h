@@ -550,4 +550,25 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
     return v;
 }
 
+// statistics are accumulated with one 64-bit atomic per wave and counter; zero contributions (idle waves of the persistent
+// kernels, background tiles) are skipped: thousands of them on the same few addresses cost more than the kernel itself
+__device__ __forceinline__ void stat_add(unsigned long long* p, uint32_t v) { if (v) atomicAdd(p, (unsigned long long)v); }
+// the same for the kernels with one workgroup per tile (tens of thousands of workgroups): the four waves first add up in
+// LDS, then one thread issues the global atomics.  Every thread of the workgroup must call it.
+__device__ __forceinline__ void block_stat_add(unsigned long long* s0, unsigned long long* s1, unsigned long long* s2, unsigned long long* s3,
+                                               uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    __shared__ unsigned int acc[4];
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0u;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(&acc[0], a);
+        if (b) atomicAdd(&acc[1], b);
+        if (c) atomicAdd(&acc[2], c);
+        if (d) atomicAdd(&acc[3], d);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { stat_add(s0, acc[0]); stat_add(s1, acc[1]); stat_add(s2, acc[2]); stat_add(s3, acc[3]); }
+    __syncthreads();                       // a second call re-initialises acc
+}
+
 }  // namespace sr
