@@ -177,6 +177,8 @@ int  sr_render(sr_scene*, const sr_frame*, int32_t* pixels, uint64_t stats[4]);
 int  sr_reset_shadow_cache(sr_scene*);
 /* Same, but `d_pixels` is DEVICE memory on the scene's device (e.g. a torch tensor's data_ptr) and the
  * work is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream) without host sync. */
+/* Ordering: the work is enqueued behind everything already on `hip_stream` and `hip_stream` continues only after it; a
+ * shadowed frame is internally forked onto two library-owned streams (event fork / join), see SR_F_NO_SPLIT. */
 int  sr_render_device(sr_scene*, const sr_frame*, void* d_pixels, void* hip_stream, uint64_t* d_stats /* device uint64[12] (see sr_last_ray_stats) or NULL */);
 /* number of int32 pixels sr_render writes for this frame (W*H, or the compact strip size) */
 int64_t sr_frame_pixel_count(const sr_frame*);

@@ -12,10 +12,11 @@ g = sa.GpuScene(0)
 g.set_triangles(v9, argb, np.array([-0.5] * 3), np.array([0.5] * 3))
 g.build((sa.MODE_BVH,))
 out = {}
+STRIP = int(os.environ.get("STRIP_ROWS", "16"))
 for n in (1, 2, 4, 8):
     times = []
     for k in range(n):
-        f = bench.make_frame(args, (16, n, k) if n > 1 else None)
+        f = bench.make_frame(args, (STRIP, n, k) if n > 1 else None)
         buf = torch.empty(g.pixel_count(f), dtype=torch.int32, device="cuda")
         s = torch.cuda.current_stream()
         for _ in range(2):
