@@ -81,12 +81,12 @@ struct sr_scene {
     // the short, latency-bound tail kernels of one half (second shaft round, fallback walks) overlap the other half's work
     static constexpr int kMaxSplit = 4;
     struct BandScratch {
-        DBuf hits, samples, counters, fallback, fallback_state, fallback_rays, fallback_ovf;
+        DBuf hits, hits2, bounce_levels, bounce_nlev, samples, counters, fallback, fallback_state, fallback_rays, fallback_ovf;
         DBuf rlist[sr::kShaftRounds], rstate[sr::kShaftRounds], rcount[sr::kShaftRounds], rcand[sr::kShaftRounds];
         hipStream_t stream = nullptr;
         hipEvent_t  done = nullptr;
         void release() {
-            DBuf* b[] = {&hits, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf};
+            DBuf* b[] = {&hits, &hits2, &bounce_levels, &bounce_nlev, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf};
             for (DBuf* x : b) x->release();
             for (int r = 0; r < sr::kShaftRounds; ++r) { rlist[r].release(); rstate[r].release(); rcount[r].release(); rcand[r].release(); }
             if (stream) (void)hipStreamDestroy(stream);
@@ -277,7 +277,10 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     } else {
         fc.flags &= ~(uint32_t)SR_F_STATIC_SHADOWS;          // meaningless without SR_F_SHADOWS (RendererTests.cs:420)
     }
-    if ((f->flags & SR_F_SINGLE_KERNEL) || f->max_bounces > 0) {      // mirror bounces: the one-kernel renderer traces them inline
+    // mirror bounces: wavefront pipeline (k_primary -> k_bounce per level -> k_fold) on the own BVH without shadows; every other
+    // combination is traced inline by the one-kernel renderer
+    const bool bounce_pipe = f->max_bounces > 0 && f->trace_mode == SR_MODE_BVH && !(f->flags & SR_F_SHADOWS) && !(f->flags & SR_F_SINGLE_KERNEL);
+    if ((f->flags & SR_F_SINGLE_KERNEL) || (f->max_bounces > 0 && !bounce_pipe)) {
         sr::RenderLaunch L{};
         L.sc = dev_scene(s);
         L.fc = fc;
@@ -314,7 +317,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     // frame (one global fill order) and shadow-less frames (one kernel) stay whole on the first set.
     int want_split = 2;
     if (const char* e = std::getenv("SR_SPLIT")) want_split = std::min(std::max(1, std::atoi(e)), (int)sr_scene::kMaxSplit);   // experiment hook
-    const bool split = shadows && !static_shadows && want_split > 1 && fc.num_rows >= 32 * want_split && !(f->flags & SR_F_NO_SPLIT);
+    const bool split = (shadows || bounce_pipe) && !static_shadows && want_split > 1 && fc.num_rows >= 32 * want_split && !(f->flags & SR_F_NO_SPLIT);
     const int halves = split ? want_split : 1;
     const int rows_half = split ? (int)((((long long)fc.num_rows + halves - 1) / halves + 15) / 16 * 16) : fc.num_rows;
     const long long budget = kMaxBandSamples / halves;
@@ -344,7 +347,14 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     }
     for (int h = 0; h < halves; ++h) {
         sr_scene::BandScratch& B = s->scratch[h];
-        if (shadows) SR_HIP(B.hits.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
+        if (shadows || bounce_pipe) SR_HIP(B.hits.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
+        if (bounce_pipe) {
+            // level colours are indexed like the sample buffer: the frame (or compact strip buffer) for one sample per pixel, band-local otherwise
+            const size_t idx_space = n2 == 1 ? (size_t)(f->strip_count > 0 ? fc.num_rows : fc.height) * fc.width : (size_t)band_samples;
+            SR_HIP(B.hits2.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
+            SR_HIP(B.bounce_levels.reserve(idx_space * (size_t)(f->max_bounces + 1) * 4));
+            SR_HIP(B.bounce_nlev.reserve(idx_space));
+        }
         if (shaft) {
             SR_HIP(B.fallback.reserve((size_t)band_samples * 4));
             SR_HIP(B.fallback_state.reserve((size_t)band_samples * sr::pipeline_round_state_bytes()));
@@ -375,6 +385,9 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.pixels = d_pixels;
         P.samples = (uint32_t*)B.samples.p;
         P.hits = B.hits.p;
+        P.hits2 = bounce_pipe ? B.hits2.p : nullptr;
+        P.bounce_levels = bounce_pipe ? (uint32_t*)B.bounce_levels.p : nullptr;
+        P.bounce_nlev = bounce_pipe ? (uint8_t*)B.bounce_nlev.p : nullptr;
         P.counters = (unsigned int*)B.counters.p;
         P.static_hits = static_shadows ? s->d_static_hits.p : nullptr;
         P.static_claim = static_shadows ? (unsigned long long*)s->d_static_claim.p : nullptr;

@@ -64,6 +64,9 @@ struct PipelineLaunch {
     void*         round_state[kShaftRounds];      // device RoundState per item (round 0: nullptr)
     unsigned int* round_cand_count[kShaftRounds]; // device per-item candidate count | truncated flag
     int32_t*      round_cand[kShaftRounds];       // device [items][pipeline_round_cap(round)] (round_cand[0] == nullptr: no shaft path)
+    void*         hits2;        // second ray queue of the mirror-bounce pipeline (same size as hits)
+    uint32_t*     bounce_levels; // device [band samples][max_bounces + 1]: colour of every level of a sample's mirror chain
+    uint8_t*      bounce_nlev;  // device [band samples]: levels stored | 0x80 when the deepest level is a surface
     void*         static_hits;  // device HitRec[min(band samples, 128^3)]: generators of a static-shadow frame
     unsigned long long* static_claim; // device [128^3]: smallest order key that asked for an empty cell
     int32_t       static_concurrency; // rayTraceConcurrency of the frame

@@ -54,7 +54,8 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 template <int MODE, bool EXTRA, bool STATS, bool SUB>
 __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
                                                  int row_count, uint32_t* __restrict__ samples, HitRec* __restrict__ hits,
-                                                 unsigned int* __restrict__ hit_count, unsigned long long* stats) {
+                                                 unsigned int* __restrict__ hit_count, uint32_t* __restrict__ bounce_levels,
+                                                 uint8_t* __restrict__ bounce_nlev, unsigned long long* stats) {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
     const int row = live ? row_map[crow] : 0;
     const int n = SUB ? fc.sub_pixel_res : 1, n2 = n * n;
     const bool shadows = (fc.flags & 2u) != 0;
+    const bool bounce = fc.max_bounces > 0;          // pipeline form of the mirror extension: never together with shadows
     const int width = fc.width, height = fc.height;
     // sample buffer: n == 1 -> the frame itself (final pixel position); n > 1 -> band-local [brow][col][n2]
     const int out_row = (fc.strip_count > 0) ? crow : row;
@@ -118,8 +120,12 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
             uint32_t color = fc.background;
             if (ok) color = (fc.flags & 1u) ? shade(fc, h.pos, h.nrm, h.color) : h.color;
             samples[sbase + si] = color;
+            if (bounce) {                                                    // level 0 of the mirror chain (see k_bounce)
+                bounce_nlev[sbase + si] = ok ? 1 : 0;
+                if (ok) bounce_levels[(sbase + si) * (size_t)(fc.max_bounces + 1)] = color;
+            }
         }
-        if (shadows) {                                                       // active-ray compaction
+        if (shadows || bounce) {                                             // active-ray compaction
             unsigned long long m = __ballot(ok);
             if (m) {
                 unsigned int base = 0;
@@ -132,6 +138,13 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
                     r.nrm[0] = h.nrm.x; r.nrm[1] = h.nrm.y; r.nrm[2] = h.nrm.z;
                     r.sample = (uint32_t)(sbase + si);
                     r.pad[0] = r.pad[1] = r.pad[2] = 0;
+                    if (bounce) {                                            // the queue holds the next RAY: origin, direction, level
+                        const D3 refl = dw - h.nrm * (2.0 * dot(dw, h.nrm));
+                        const D3 org = h.pos + h.nrm * 0.001;
+                        r.pos[0] = org.x; r.pos[1] = org.y; r.pos[2] = org.z;
+                        r.nrm[0] = refl.x; r.nrm[1] = refl.y; r.nrm[2] = refl.z;
+                        r.pad[0] = 1u;
+                    }
                     hits[base + (unsigned int)__popcll(m & lanemask_lt())] = r;
                 }
             }
@@ -1093,6 +1106,203 @@ __global__ __launch_bounds__(256) void k_resolve(FrameConst fc, const int32_t* _
 }
 
 // --------------------------------------------------------------------------------------------------
+// Mirror bounces (config-5 extension, definition in trace_camera_ray / the CPU checker) as a wavefront pipeline: the
+// queue holds one RAY per surviving sample (origin = hit + n * 0.001, direction = the reflection, level); k_bounce finds
+// its nearest hit, stores that level's colour and queues the next reflection; k_fold blends the levels back to front.
+// Secondary rays are incoherent, so k_bounce uses persistent lanes refilled from the queue (cf. k_shadow_rays); the walk
+// is root_intersect<MODE_BVH, false, EXTRA> (extra geometry first, then bvh_intersect<false>) as a per-lane state machine.
+// --------------------------------------------------------------------------------------------------
+template <bool EXTRA, bool STATS>
+__global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, const HitRec* __restrict__ qin, const unsigned int* __restrict__ qin_count,
+                                                HitRec* __restrict__ qout, unsigned int* __restrict__ qout_count, unsigned int* __restrict__ head,
+                                                uint32_t* __restrict__ levels, uint8_t* __restrict__ nlev, unsigned long long* stats) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
+    const unsigned int total = *qin_count;
+    const float kInfl = 1.0f + 9.5367431640625e-7f;          // 1 + 2^-20
+    const int maxb = fc.max_bounces;
+    Ctr sec = {0, 0, 0, 0};
+    // ---- per ray ----
+    uint32_t sample = 0, level = 0;
+    D3 s0 = mk(0, 0, 0), d = mk(0, 0, 0);      // the ray as queued (unclipped)
+    D3 s = mk(0, 0, 0);                        // clipped start (SpatialSubdivision.cs:394)
+    double offset = 0.0, best = DBL_MAX;
+    int32_t bestIdx = 0x7fffffff, bestK = -1;
+    double ex_t = DBL_MAX;                     // nearest extra-geometry hit (GeometryCollection order, strict '<')
+    D3 ex_pos = mk(0, 0, 0), ex_nrm = mk(0, 0, 0);
+    uint32_t ex_color = 0;
+    f2 I01 = splat(0.0f), I20 = I01, I12 = I01, B0 = I01, B1 = I01, B2 = I01;
+    float tlim = FLT_MAX;
+    int sp = 0;
+    int32_t ni = -1, leafA = -1, leafB = -1;
+    bool active = false, walking = false;
+    bool drained = false;
+    for (;;) {
+        const unsigned long long busy = __ballot(active);
+        if (!drained && (int)__popcll(busy) <= kRaysRefillAt) {
+            const unsigned long long m = ~busy;
+            unsigned int base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(head, (unsigned int)__popcll(m));
+            base = __shfl(base, leader, 64);
+            drained = base + (unsigned int)__popcll(m) >= total;
+            if (!active) {
+                const unsigned int r = base + (unsigned int)__popcll(m & lanemask_lt());
+                if (r < total) {
+                    const HitRec q = qin[r];
+                    sample = q.sample; level = q.pad[0];
+                    s0 = mk(q.pos[0], q.pos[1], q.pos[2]);
+                    d = mk(q.nrm[0], q.nrm[1], q.nrm[2]);
+                    sec.rays++;
+                    ex_t = DBL_MAX;
+                    if (EXTRA) {                                                   // root_intersect: the extras, first to last
+                        for (int i = 0; i < sc.nextra; ++i) {
+                            const Rec128* e = &sc.extra[i];
+                            double t; D3 pos, nrm;
+                            bool ok;
+                            const int kind = e->aux;
+                            if (kind == 0) ok = sphere_hit(e->p, s0, d, t, pos, nrm);
+                            else if (kind == 1) { ok = plane_hit(e->p, s0, d, t, pos); nrm = mk(e->p[0], e->p[1], e->p[2]); }
+                            else { ok = tri_hit(e->p, s0, d, t, pos); nrm = mk(e->p[0], e->p[1], e->p[2]); }
+                            sec.geom++;
+                            if (ok && t < ex_t) { ex_t = t; ex_pos = pos; ex_nrm = nrm; ex_color = e->color; }
+                        }
+                    }
+                    // bvh_intersect<false>: clip, rayFracOffset, fp32 culling frame
+                    best = DBL_MAX; bestIdx = 0x7fffffff; bestK = -1;
+                    s = s0;
+                    D3 end = s + d * 10000.0;
+                    walking = clip_segment<false>(sc.root, s, end);
+                    if (walking) {
+                        offset = length(s0 - s) / length(d);
+                        const float ox = (float)(s.x - sc.root.centre[0]), oy = (float)(s.y - sc.root.centre[1]), oz = (float)(s.z - sc.root.centre[2]);
+                        const float ix = slab_inv((float)d.x), iy = slab_inv((float)d.y), iz = slab_inv((float)d.z);
+                        I01 = (f2){ix, iy}; I20 = (f2){iz, ix}; I12 = (f2){iy, iz};
+                        B0 = (f2){-ox * ix, -oy * iy}; B1 = (f2){-oz * iz, -ox * ix}; B2 = (f2){-oy * iy, -oz * iz};
+                        tlim = FLT_MAX;
+                        sp = 0; ni = 0; leafA = -1; leafB = -1;
+                    } else {
+                        ni = -1; leafA = -1; leafB = -1;
+                    }
+                    active = true;
+                }
+            }
+        }
+        if (!__any(active)) break;
+        if (active) {
+            while (ni >= 0 && leafA < 0) {
+                const BvhNode n = sc.bnodes[ni];
+                sec.nodes++;
+                float t0, x0, t1, x1;
+                node_slabs(n, I01, I20, I12, B0, B1, B2, t0, x0, t1, x1);
+                const bool h0 = n.n0 >= 0 && t0 <= x0 && x0 >= 0.0f && t0 <= tlim;
+                const bool h1 = n.n1 >= 0 && t1 <= x1 && x1 >= 0.0f && t1 <= tlim;
+                const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
+                if (l0 && l1) {                                   // nearer leaf first
+                    const bool first0 = t0 <= t1;
+                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << 28);
+                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << 28);
+                } else if (l0) leafA = n.c0 | (n.n0 << 28);
+                else if (l1) leafA = n.c1 | (n.n1 << 28);
+                const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
+                if (i0 && i1) {
+                    const bool first0 = t0 <= t1;
+                    st.put(sp++, first0 ? n.c1 : n.c0);           // the far child is re-tested against tlim when it is popped
+                    ni = first0 ? n.c0 : n.c1;
+                } else if (i0) ni = n.c0;
+                else if (i1) ni = n.c1;
+                else ni = (sp > 0) ? st.get(--sp) : -1;
+            }
+            while (leafA >= 0) {
+                const int32_t first = leafA & 0x0fffffff, cn = (leafA >> 28) & 7;
+                leafA = leafB;
+                leafB = -1;
+                sec.leaves++;
+                for (int k = first; k < first + cn; ++k) {
+                    const Rec128* r = &sc.btris[k];
+                    double t; D3 pos;
+                    sec.geom++;
+                    if (tri_hit(r->p, s, d, t, pos) && inside(sc.root.lo, sc.root.hi, pos)) {
+                        const int32_t idx = r->aux;
+                        if (t < best || (t == best && idx < bestIdx)) {
+                            best = t; bestIdx = idx; bestK = k;
+                            tlim = (float)best * kInfl + 1e-30f;
+                        }
+                    }
+                }
+            }
+            if (ni < 0 && leafA < 0) {
+                // ---- the ray is finished: nearest of {extras, model}, colour of this level, next reflection ----
+                bool hit = false;
+                D3 hpos = ex_pos, hnrm = ex_nrm;
+                uint32_t hcol = ex_color;
+                if (ex_t < DBL_MAX) hit = true;
+                if (walking && bestK >= 0 && (best + offset) < ex_t) {
+                    const Rec128* r = &sc.btris[bestK];
+                    hit = true;
+                    hpos = s + d * best;
+                    hnrm = mk(r->p[0], r->p[1], r->p[2]);
+                    hcol = r->color;
+                }
+                if (hit) {
+                    uint32_t color = hcol;
+                    if (fc.flags & 1u) color = shade(fc, hpos, hnrm, color);
+                    levels[(size_t)sample * (size_t)(maxb + 1) + level] = color;
+                    const uint32_t nl = level + 1u;
+                    if ((int)nl > maxb) {
+                        nlev[sample] = (uint8_t)(nl | 0x80u);                  // the deepest level is a surface: nothing beyond it
+                    } else {
+                        nlev[sample] = (uint8_t)nl;
+                        HitRec o;
+                        const D3 refl = d - hnrm * (2.0 * dot(d, hnrm));
+                        const D3 org = hpos + hnrm * 0.001;
+                        o.pos[0] = org.x; o.pos[1] = org.y; o.pos[2] = org.z;
+                        o.nrm[0] = refl.x; o.nrm[1] = refl.y; o.nrm[2] = refl.z;
+                        o.sample = sample;
+                        o.pad[0] = nl; o.pad[1] = o.pad[2] = 0;
+                        qout[atomicAdd(qout_count, 1u)] = o;                   // the compiler aggregates this per wavefront
+                    }
+                }
+                active = false;
+            }
+        }
+    }
+    if (STATS) {
+        uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom), c2 = wave_sum(sec.nodes), d2 = wave_sum(sec.leaves);
+        if (lane == 0) { stat_add(&stats[4], a); stat_add(&stats[5], b); stat_add(&stats[6], c2); stat_add(&stats[7], d2); }
+    }
+}
+
+// blend the stored levels of every sample back to front (the fold of trace_camera_ray)
+__global__ __launch_bounds__(256) void k_fold(FrameConst fc, long long nsamples, const uint32_t* __restrict__ levels, const uint8_t* __restrict__ nlev,
+                                              uint32_t* __restrict__ samples, const int32_t* __restrict__ row_map, int row_begin, int row_count) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;            // band-local sample position
+    if (i >= nsamples) return;
+    const int n2 = fc.sub_pixel_res * fc.sub_pixel_res;
+    // position in the sample buffer: n == 1 -> the frame (image or compact strip row), n > 1 -> band-local
+    size_t sidx = (size_t)i;
+    if (n2 == 1) {
+        const int brow = (int)(i / fc.width), col = (int)(i - (long long)brow * fc.width);
+        const int crow = row_begin + brow;
+        const int out_row = (fc.strip_count > 0) ? crow : row_map[crow];
+        sidx = (size_t)out_row * fc.width + col;
+    }
+    const uint32_t code = nlev[sidx];
+    const int nl = (int)(code & 0x7fu);
+    if (nl == 0) return;                                                       // the camera ray missed: background, already stored
+    const bool tail_is_surface = (code & 0x80u) != 0;
+    const uint32_t* sf = levels + sidx * (size_t)(fc.max_bounces + 1);
+    const uint32_t k = to_byte(fc.reflectivity * 255.0);
+    uint32_t color = fc.background;
+    const int last = tail_is_surface ? nl - 2 : nl - 1;
+    for (int l = nl - 1; l >= 0; --l) {
+        if (tail_is_surface && l == nl - 1) color = sf[l];
+        if (l <= last) color = blend_packed(sf[l], color, k);
+    }
+    samples[sidx] = color;
+}
+
+// --------------------------------------------------------------------------------------------------
 // rayTraceShadowsStatic (ShadowMethod.cs:75-83,103-108, Texture3DCache.cs:95-135): the light fraction of a surface
 // point is looked up in a 128^3 byte texture over the unit cube; an empty cell is generated by whoever asks first.
 // The reference's worker tasks race for that; the CPU checker pins a deterministic order against the reference's two
@@ -1171,10 +1381,10 @@ static hipError_t launch_primary_s(const PipelineLaunch& L, int row_begin, int r
     size_t lds = (size_t)pipe_stack_levels(L.sc, MODE) * 256 * 4;
     if (L.stats)
         hipLaunchKernelGGL((k_primary<MODE, EXTRA, true, SUB>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
-                           samples, (HitRec*)L.hits, L.counters, L.stats);
+                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats);
     else
         hipLaunchKernelGGL((k_primary<MODE, EXTRA, false, SUB>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
-                           samples, (HitRec*)L.hits, L.counters, L.stats);
+                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats);
     return hipGetLastError();
 }
 
@@ -1298,7 +1508,7 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
         int row_count = std::min(L.band_rows, L.row_limit - row_begin);
         uint32_t* samples = (n2 == 1) ? L.pixels : L.samples;
         hipError_t e;
-        if (shadows) {
+        if (shadows || L.fc.max_bounces > 0) {
             e = hipMemsetAsync(L.counters, 0, 16 * sizeof(unsigned int), L.stream);
             if (e != hipSuccess) return e;
         }
@@ -1309,7 +1519,31 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
                                    : launch_primary_s<MODE, EXTRA, false>(L, row_begin, row_count, samples);
         if (e != hipSuccess) return e;
         if (e1) { e = hipEventRecord(e1, L.stream); if (e != hipSuccess) return e; }
-        if (shadows && (L.fc.flags & 32u)) {
+        if (L.fc.max_bounces > 0 && L.bounce_levels) {
+            // ---- mirror bounces as a wavefront pipeline: one k_bounce per level, the queues ping-pong ----
+            // counters: [0] / [1] ray counts of the two queues  [2] k_bounce's work head
+            const long long band_n = (long long)row_count * L.fc.width * n2;
+            hipEvent_t b0 = nullptr, b1 = nullptr;
+            if (L.get_events) L.get_events(L.user, K_FALLBACK, &b0, &b1);       // reported as "k_shadow_fallback": the secondary-ray family
+            if (b0 && (e = hipEventRecord(b0, L.stream)) != hipSuccess) return e;
+            const size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
+            const unsigned blocks = (unsigned)std::min<long long>((band_n + 255) / 256, (long long)L.persistent_blocks);
+            int cur = 0;
+            for (int level = 1; level <= L.fc.max_bounces; ++level) {
+                if ((e = hipMemsetAsync(L.counters + (1 - cur), 0, 4, L.stream)) != hipSuccess) return e;
+                if ((e = hipMemsetAsync(L.counters + 2, 0, 4, L.stream)) != hipSuccess) return e;
+                const HitRec* qin = (const HitRec*)(cur == 0 ? L.hits : L.hits2);
+                HitRec* qout = (HitRec*)(cur == 0 ? L.hits2 : L.hits);
+                if (L.stats) hipLaunchKernelGGL((k_bounce<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, qin, L.counters + cur, qout, L.counters + (1 - cur), L.counters + 2, L.bounce_levels, L.bounce_nlev, L.stats);
+                else hipLaunchKernelGGL((k_bounce<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, qin, L.counters + cur, qout, L.counters + (1 - cur), L.counters + 2, L.bounce_levels, L.bounce_nlev, L.stats);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+                cur = 1 - cur;
+            }
+            hipLaunchKernelGGL(k_fold, dim3((unsigned)((band_n / n2 * n2 + 255) / 256)), dim3(256), 0, L.stream, L.fc, band_n, (const uint32_t*)L.bounce_levels,
+                               (const uint8_t*)L.bounce_nlev, samples, L.row_map, row_begin, row_count);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if (b1 && (e = hipEventRecord(b1, L.stream)) != hipSuccess) return e;
+        } else if (shadows && (L.fc.flags & 32u)) {
             // ---- static frame: claim cells, run the shadow kernels on the generators only, apply the cache ----
             // counters: [0] hit points of the band  [13] generators  [14] copy of [0] while the generators are processed
             const long long max_hits = (long long)row_count * L.fc.width * n2;

@@ -420,6 +420,28 @@ def test_reflection_extension_matches_oracle():
     want, _ = o.render(f, threads=NCPU)
     got, _ = g.render(as_sr(f, sa.MODE_BVH))
     assert np.array_equal(got, want)
+    # the wavefront form (k_primary -> k_bounce per level -> k_fold, the default on the own BVH without shadows) against the
+    # one-kernel renderer, in one piece, in bands, as one pipeline and as interleaved strips
+    single, st1 = g.render(as_sr(f, sa.MODE_BVH, single_kernel=True))
+    assert np.array_equal(single, want)
+    nosplit = as_sr(f, sa.MODE_BVH); nosplit.flags |= sa._lib.F_NO_SPLIT
+    assert np.array_equal(g.render(nosplit)[0], want)
+    monkey_env = dict(os.environ)
+    os.environ["SR_BAND_SAMPLES"] = "3000"
+    try:
+        assert np.array_equal(g.render(as_sr(f, sa.MODE_BVH))[0], want)
+        f2 = make_frame(96, depth=1.5, sub_pixel_res=2)
+        f2.max_bounces, f2.reflectivity = 3, 0.6
+        assert np.array_equal(g.render(as_sr(f2, sa.MODE_BVH))[0], o.render(f2, threads=NCPU)[0])
+    finally:
+        os.environ.clear(); os.environ.update(monkey_env)
+    full = want.reshape(96, 96)
+    for k in range(3):
+        fs = make_frame(96, depth=1.5, strips=(8, 3, k))
+        fs.max_bounces, fs.reflectivity = 4, 0.4
+        px, _ = g.render(as_sr(fs, sa.MODE_BVH))
+        rows = [r for r in range(96) if (r // 8) % 3 == k]
+        assert np.array_equal(px.reshape(len(rows), 96), full[rows]), k
 
 
 def test_device_built_bvh_gives_identical_pixels():
