@@ -340,9 +340,9 @@ __device__ __forceinline__ bool tri_blocks(const double* p, const SampleRay& r, 
 }
 
 constexpr int kPacketSlots = 2;          // samples per lane in k_shadow_test: S <= 128
-constexpr int kShaftCap = 64;            // triangles per candidate list in the first round (every hit)
+constexpr int kShaftCap = 32;            // triangles per candidate list in the first round (every hit)
 // later rounds only see the hits whose earlier candidates left samples undecided: longer lists, fewer hits
-constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 64};
+constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 32};
 constexpr int kRecordsPerPass = 16;      // records staged through LDS per pass (2 KB per wave)
 // LDS strides (bank = address / 4 mod 64): in the (sample x candidate) layout the lanes of a wave read up to 8 different
 // records and up to 64 different rays at once; 144-byte records and 80-byte rays spread those over the banks
@@ -365,6 +365,7 @@ constexpr unsigned kUmbraItem = 0x40000000u;   // cand_count of a later round: k
 struct ShaftRay {
     f2    edx, edy, edz;        // per axis (E' , L - E'): value and slope of the centre ray C(u) = E' + u (L - E')
     float R, pad, ext, hbx, hby, hbz;
+    float backface;             // R * 1.001 + 1e-6 * |L - E'|_1: see shaft_touches
 };
 
 // reciprocal slope of a linear function f0 + u f1; a (nearly) zero slope acts as a huge positive one: the function is
@@ -400,6 +401,10 @@ __device__ __forceinline__ int shaft_touches(const TriSlab s, const ShaftRay& sr
     const f2 P = pk_fma(splat(s.m1[0]), sr.edx, pk_fma(splat(s.m1[1]), sr.edy, pk_fma(splat(s.m1[2]), sr.edz, c1)));
     const f2 Q = pk_fma(splat(s.m2[0]), sr.edx, pk_fma(splat(s.m2[1]), sr.edy, pk_fma(splat(s.m2[2]), sr.edz, c2)));
     const f2 T = pk_fma(splat(s.m3[0]), sr.edx, pk_fma(splat(s.m3[1]), sr.edy, pk_fma(splat(s.m3[2]), sr.edz, c3)));
+    // Triangle.IntersectRay is one-sided (dirDist >= 0 -> no hit, Triangle.cs / Plane.cs:60-61): dirDist of sample i is
+    // -n.(D + off_i) with |n.off_i| <= R, so a triangle with n.D + R < 0 faces away from EVERY sample ray and can never block
+    // one.  backface = R + fp32 slack (plane rounding + dot product, < 1e-6 |D|_1), computed per hit point.
+    if (N.y < -sr.backface) return 0;
     const float in = slope_inv(N.y), ip = slope_inv(P.y), iq = slope_inv(Q.y), it3 = slope_inv(T.y);
     const float bp = __builtin_copysignf(1e30f, ip), bq = __builtin_copysignf(1e30f, iq), bt = __builtin_copysignf(1e30f, it3);
     // the shaft radius at the far end of the current interval bounds the deviation; clipping shrinks the interval,
@@ -471,6 +476,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         ShaftRay sr;
         sr.edx = (f2){ex, dx}; sr.edy = (f2){ey, dy}; sr.edz = (f2){ez, dz};
         sr.R = R; sr.pad = pad_tri; sr.ext = ext;
+        sr.backface = R * 1.001f + 1e-6f * (fabsf(dx) + fabsf(dy) + fabsf(dz)) + 1e-30f;
         sr.hbx = 0.5f * (float)(sc.root.max[0] - sc.root.min[0]); sr.hby = 0.5f * (float)(sc.root.max[1] - sc.root.min[1]); sr.hbz = 0.5f * (float)(sc.root.max[2] - sc.root.min[2]);
         const int nbits = sc.bnode_bits, qmax = (1 << (31 - nbits)) - 1;   // stack word = node | quantised u bound
         const float qinv = 1.0f / (float)qmax * 1.000001f;
