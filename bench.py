@@ -131,12 +131,14 @@ def main():
     ap.add_argument("--depth", type=float, default=1.5)
     ap.add_argument("--no-split", action="store_true", help="SR_F_NO_SPLIT for every frame: one pipeline, no overlapping kernels")
     ap.add_argument("--static-shadows", action="store_true", help="rayTraceShadowsStatic (cache reset before every step: cold cache)")
-    ap.add_argument("--bounces", type=int, default=0, help="config-5 extension: mirror bounces (unpinned; one-kernel renderer)")
+    ap.add_argument("--bounces", type=int, default=0, help="config-5 extension: mirror bounces (parity unpinned; wavefront bounce pipeline on the own BVH)")
     ap.add_argument("--reflectivity", type=float, default=0.5)
     ap.add_argument("--extent", type=float, default=0.05, help="triangle extent of the synthetic soup (SURVEY 8d: 0.05 at 1M, 0.02 at 10M)")
     ap.add_argument("--strip-rows", type=int, default=16)
     ap.add_argument("--device-build", action="store_true", help="build the BVH on the GPU (LBVH) instead of the host SAH builder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-shadow-tests", action="store_true", help="k_shadow_test (every pair in FP64) instead of the fp32-classified k_shadow_cls")
+    ap.add_argument("--dbg", action="append", default=[], metavar="KEY=VALUE", help="sr_debug_set hook, e.g. --dbg 1=16 (SR_DBG_ROUND_CAP0 = 16)")
     ap.add_argument("--verify", action="store_true", help="after timing: rank 0 re-renders the whole frame alone and compares it with the gathered one")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
     args = ap.parse_args()
@@ -163,6 +165,11 @@ def main():
     bmin, bmax = np.array([-0.5] * 3), np.array([0.5] * 3)
     g = sa.GpuScene(local_rank)
     g.set_triangles(v9, argb, bmin, bmax)
+    if args.exact_shadow_tests:
+        g.debug_set(sa._lib.DBG_EXACT_SHADOW_TESTS, 1)
+    for kv in args.dbg:
+        k, v = kv.split("=")
+        g.debug_set(int(k), int(v))
     t0 = time.time()
     g.build(({"bvh": sa.MODE_BVH, "ref": sa.MODE_REF_TREE}.get(args.mode),) if args.mode != "brute" else (),
             on_device=args.device_build and args.mode == "bvh")
@@ -210,6 +217,7 @@ def main():
     frame_ns.flags |= sa._lib.F_NO_SPLIT
     if frame.area_light_offsets:
         frame_ns.area_light_offsets = frame.area_light_offsets
+    g.debug_set(sa._lib.DBG_KERNEL_TIMING, 1)                         # event pairs around every launch: only in this extra pass
     g.render_device(frame_ns, local.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize(dev)
     g.reset_kernel_times()
@@ -219,6 +227,7 @@ def main():
     torch.cuda.synchronize(dev)
     ms_unsplit = (time.perf_counter() - t1) / args.steps * 1e3
     kt = {k: (ms / max(1, n), n) for k, (ms, n) in g.kernel_times().items()}
+    g.debug_set(sa._lib.DBG_KERNEL_TIMING, -1)
 
     primary_rays = args.res * args.res * args.spp * args.spp
     value = primary_rays * args.steps / elapsed / 1e6
@@ -238,7 +247,8 @@ def main():
         algo = {
             "k_primary": S_PIX * npix + rs[2] * S_NODE + rs[1] * S_TRI + 64.0 * (rs[4] / max(1, args.shadows) if args.shadows else 0),
             "k_shaft": rs[11] * 64.0 + rs[6] * S_NODE + rs[10] * 64.0 + rs[8] * 4.0,
-            "k_shadow": rs[9] * (64.0 + 4.0 + 8.0) + rs[8] * (S_TRI + 4.0),
+            # k_shadow_cls reads the 64-byte fp32 TriSlab of a candidate (k_shadow_test, the FP64 cross-check, its 128-byte record)
+            "k_shadow": rs[9] * (64.0 + 4.0 + 8.0) + rs[8] * ((S_TRI if args.exact_shadow_tests else 64.0) + 4.0),
             "k_render": per_ray_touch,
         }
         tot = {k: v[0] * v[1] for k, v in kt.items()}                 # total ms per kernel over the timed steps
@@ -285,9 +295,9 @@ def main():
             "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d random triangles (System.Random seed 12345, extent 0.05, unit cube) + BVH, %dx%d, "
+            "config": {"workload": "%d random triangles (System.Random seed 12345, extent %g, unit cube) + BVH, %dx%d, "
                                    "spp %d, shading + %d shadow samples/hit, pose yaw135/pitch-22/depth %.1f" % (
-                                       args.tris, args.res, args.res, args.spp * args.spp, args.shadows, args.depth),
+                                       args.tris, args.extent, args.res, args.res, args.spp * args.spp, args.shadows, args.depth),
                        "trace_mode": args.mode, "parallelism": "rows x%d (interleaved %d-row strips)" % (world, args.strip_rows)},
             "rays_rank0": {"primary": rs[0], "shadow": rs[4], "tri_tests": rs[1] + rs[5], "node_visits": rs[2] + rs[6],
                            "primary_plus_shadow_Mrays_per_s": ((rs[0] + rs[4]) / (ms_per_step * 1e-3) / 1e6) if world == 1 else None},
@@ -306,6 +316,7 @@ def main():
             "kernels_ms": {k: v[0] for k, v in kt.items()}, "kernel_launches": {k: v[1] for k, v in kt.items()},
             "ms_per_step_one_pipeline": ms_unsplit,
             "pipeline_counters_last_band": g.debug_counters(), "device_counters": [float(x) for x in rs],
+            "shadow_pairs": {"classified_fp32": rs[12], "decided_fp64": rs[13], "fp64_fraction": (rs[13] / rs[12]) if rs[12] else None},
             "build_s": build_s, "d2h_ms": d2h_ms,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -336,6 +347,7 @@ def main():
     if world == 1 and rank == 0:
         n = args.res * args.res
         aa_dst = torch.empty(n // 4, dtype=torch.int32, device=dev)
+        g.debug_set(sa._lib.DBG_KERNEL_TIMING, 1)
         g.reset_kernel_times()
         reps = 20
         for _ in range(reps):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 2
+#define SR_ABI_VERSION 3
 
 enum {
     SR_OK                 =  0,
@@ -179,7 +179,7 @@ int  sr_reset_shadow_cache(sr_scene*);
  * work is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream) without host sync. */
 /* Ordering: the work is enqueued behind everything already on `hip_stream` and `hip_stream` continues only after it; a
  * shadowed frame is internally forked onto two library-owned streams (event fork / join), see SR_F_NO_SPLIT. */
-int  sr_render_device(sr_scene*, const sr_frame*, void* d_pixels, void* hip_stream, uint64_t* d_stats /* device uint64[12] (see sr_last_ray_stats) or NULL */);
+int  sr_render_device(sr_scene*, const sr_frame*, void* d_pixels, void* hip_stream, uint64_t* d_stats /* device uint64[16] (see sr_last_ray_stats) or NULL */);
 /* number of int32 pixels sr_render writes for this frame (W*H, or the compact strip size) */
 int64_t sr_frame_pixel_count(const sr_frame*);
 
@@ -208,7 +208,7 @@ int  sr_load_3ds(sr_scene*, const uint8_t* data, size_t len);
 int64_t sr_num_triangles(const sr_scene*);
 int  sr_get_triangles(const sr_scene*, double* v9, uint32_t* argb, double box_min[3], double box_max[3]);
 
-/* Device time of the library's kernels, measured with one HIP event pair per launch on the launch stream and
+/* Device time of the library's kernels (opt-in: sr_debug_set(SR_DBG_KERNEL_TIMING, 1)), measured with one HIP event pair per launch on the launch stream and
  * accumulated since sr_reset_kernel_times() (or scene creation): out[i] = {static kernel name, total ms,
  * launches}.  sr_kernel_times waits for the recorded events.  Returns the number of entries (<= cap). */
 typedef struct { const char* name; float ms; int32_t launches; } sr_kernel_time;
@@ -218,9 +218,10 @@ int  sr_kernel_times(sr_scene*, sr_kernel_time* out, int32_t cap);
 /* Ray statistics of the last sr_render(..., stats != NULL): [0..3] primary rays {rays, triangle/primitive tests, nodes
  * visited, leaf nodes visited}; [4..7] the same for secondary (shadow) rays -- on the shaft path [6],[7] are the shaft
  * walks' nodes / leaves; [8] triangle records staged through LDS by k_shadow_test, [9] hit points it processed,
- * [10] fp32 slab records read by k_shaft, [11] hit points it walked.  These are the counters the roofline's
+ * [10] fp32 slab records read by k_shaft, [11] hit points it walked, [12] (sample, triangle) pairs k_shadow_test classified
+ * in fp32, [13] pairs it had to decide with the exact FP64 test, [14..15] reserved.  These are the counters the roofline's
  * algorithmic bytes are priced from (DESIGN.md "Measurement"). */
-int  sr_last_ray_stats(const sr_scene*, uint64_t out[12]);
+int  sr_last_ray_stats(const sr_scene*, uint64_t out[16]);
 
 /* Seeded synthetic triangle soup = SpatialSubdivisionTests.MakeRandomTriangles
  * (Engine3D-Tests/Raytrace/SpatialSubdivisionTests.cs:397-411) driven by the System.Random port: per triangle
@@ -250,6 +251,23 @@ int  sr_post_process_device(sr_scene*, void* d_pixels, int64_t count, int32_t st
 int  sr_anti_alias(sr_scene*, const int32_t* src, int32_t dst_width, int32_t dst_height, int32_t resolution, int32_t* dst);
 int  sr_anti_alias_device(sr_scene*, const void* d_src, int32_t dst_width, int32_t dst_height, int32_t resolution, void* d_dst,
                           void* hip_stream);
+
+/* Test / experiment hooks of ONE scene.  The library never reads the process environment: a drop-in must not change its
+ * schedule with the host's env.  value < 0 restores the default.  Used by tests/ and scripts/ only. */
+enum {
+    SR_DBG_BAND_SAMPLES   = 0,   /* samples per row band (default 16 Mi / 32 Mi): small values force several bands             */
+    SR_DBG_ROUND_CAP0     = 1,   /* candidate-list length of shaft round 1 (<= 32)                                             */
+    SR_DBG_ROUND_CAP1     = 2,   /* ... of round 2 (<= 32): tiny lists force round 2 and the exact fallback                    */
+    SR_DBG_SPLIT          = 3,   /* concurrent part-frame pipelines (default 2, <= 4)                                          */
+    SR_DBG_FB_RAY_CAP     = 4,   /* capacity of the fallback ray list                                                          */
+    SR_DBG_BVH_LEAF       = 5,   /* triangles per leaf of the host SAH build (default 4, 1..7); read by the next sr_build      */
+    SR_DBG_KERNEL_SWITCH  = 6,   /* FrameConst.debug: kernel-internal experiment switch (0 = production)                       */
+    SR_DBG_KERNEL_TIMING  = 7,   /* > 0: record a HIP event pair around every launch (sr_kernel_times); default off           */
+    SR_DBG_EXACT_SHADOW_TESTS = 8, /* > 0: k_shadow_test decides every (sample, triangle) pair with the FP64 arithmetic (no
+                                    fp32 classification): an independent schedule of the same result, kept as a cross-check */
+    SR_DBG_COUNT          = 16
+};
+int  sr_debug_set(sr_scene*, int32_t key, int64_t value);
 
 /* Diagnostics only: the pipeline's device counters after the last row band of the last frame
  * {hit points queued, per-lane shadow work head, hit points that needed the long (round-2) candidate list,

@@ -102,7 +102,9 @@ struct sr_scene {
     // kernel timing: one HIP event pair per launch, accumulated until sr_reset_kernel_times()
     std::vector<hipEvent_t> ev[sr::K_COUNT];       // [2*i] start, [2*i+1] stop
     int  ev_used[sr::K_COUNT] = {};
-    uint64_t last_stats[12] = {};
+    uint64_t last_stats[16] = {};
+    int64_t dbg[SR_DBG_COUNT];             // sr_debug_set hooks, -1 = default (never read from the environment)
+    sr_scene() { for (auto& d : dbg) d = -1; }
 };
 
 namespace {
@@ -230,7 +232,7 @@ int prepare_frame(sr_scene* s, const sr_frame* f, sr::FrameConst& fc) {
         r2max = std::max(r2max, o[0] * o[0] + o[1] * o[1] + o[2] * o[2]);
     }
     fc.light_radius = std::sqrt(r2max);
-    { const char* dbg = std::getenv("SR_DEBUG"); fc.debug = dbg ? std::atoi(dbg) : 0; }
+    fc.debug = s->dbg[SR_DBG_KERNEL_SWITCH] > 0 ? (int32_t)s->dbg[SR_DBG_KERNEL_SWITCH] : 0;
     return SR_OK;
 }
 
@@ -239,6 +241,7 @@ const int kMaxTimedLaunches = 4096;
 // hands out the event pair for the next launch of kernel k (nullptr once the pool is exhausted)
 int next_events(sr_scene* s, int k, hipEvent_t& a, hipEvent_t& b) {
     a = b = nullptr;
+    if (s->dbg[SR_DBG_KERNEL_TIMING] <= 0) return SR_OK;          // opt-in: no events inside an ordinary frame
     if (s->ev_used[k] >= kMaxTimedLaunches) return SR_OK;
     if ((size_t)(2 * s->ev_used[k] + 2) > s->ev[k].size()) {
         hipEvent_t e0, e1;
@@ -307,16 +310,16 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     long long kMaxBandSamples = shaft ? (16ll << 20) : (32ll << 20);
     int round_cap[sr::kShaftRounds];
     for (int r = 0; r < sr::kShaftRounds; ++r) round_cap[r] = sr::pipeline_round_cap(r);
-    {   // test hooks: shrink the bands / candidate lists so that small frames exercise banding, round 2 and the fallback
-        if (const char* e = std::getenv("SR_BAND_SAMPLES")) kMaxBandSamples = std::max(1ll, std::atoll(e));
-        if (const char* e = std::getenv("SR_ROUND_CAP0")) round_cap[0] = std::min(std::max(1, std::atoi(e)), sr::pipeline_round_cap(0));
-        if (const char* e = std::getenv("SR_ROUND_CAP1")) round_cap[1] = std::min(std::max(1, std::atoi(e)), sr::pipeline_round_cap(1));
+    {   // test hooks (sr_debug_set): shrink the bands / candidate lists so that small frames exercise banding, round 2 and the fallback
+        if (s->dbg[SR_DBG_BAND_SAMPLES] > 0) kMaxBandSamples = s->dbg[SR_DBG_BAND_SAMPLES];
+        if (s->dbg[SR_DBG_ROUND_CAP0] > 0) round_cap[0] = (int)std::min<int64_t>(s->dbg[SR_DBG_ROUND_CAP0], sr::pipeline_round_cap(0));
+        if (s->dbg[SR_DBG_ROUND_CAP1] > 0) round_cap[1] = (int)std::min<int64_t>(s->dbg[SR_DBG_ROUND_CAP1], sr::pipeline_round_cap(1));
     }
     // Two halves of the frame (16-row granularity) run as two pipelines on two internal streams, each with its own scratch
     // set; a half that exceeds its share of the band budget is processed in sequential bands on its stream.  A static
     // frame (one global fill order) and shadow-less frames (one kernel) stay whole on the first set.
     int want_split = 2;
-    if (const char* e = std::getenv("SR_SPLIT")) want_split = std::min(std::max(1, std::atoi(e)), (int)sr_scene::kMaxSplit);   // experiment hook
+    if (s->dbg[SR_DBG_SPLIT] > 0) want_split = (int)std::min<int64_t>(s->dbg[SR_DBG_SPLIT], (int)sr_scene::kMaxSplit);   // experiment hook
     const bool split = (shadows || bounce_pipe) && !static_shadows && want_split > 1 && fc.num_rows >= 32 * want_split && !(f->flags & SR_F_NO_SPLIT);
     const int halves = split ? want_split : 1;
     const int rows_half = split ? (int)((((long long)fc.num_rows + halves - 1) / halves + 15) / 16 * 16) : fc.num_rows;
@@ -332,7 +335,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     // sample = 0.4 GB for a 4096^2 frame; whatever it has no room for is taken by the one-wave-per-hit kernel.  Test hook
     // SR_FB_RAY_CAP shrinks it
     long long fallback_ray_cap = std::min<long long>(6 * band_samples, 0xfffffff0ll);
-    if (const char* e = std::getenv("SR_FB_RAY_CAP")) fallback_ray_cap = std::max(1ll, std::atoll(e));
+    if (s->dbg[SR_DBG_FB_RAY_CAP] > 0) fallback_ray_cap = s->dbg[SR_DBG_FB_RAY_CAP];
     unsigned round_items[sr::kShaftRounds] = {};
     for (int r = 0; r < sr::kShaftRounds; ++r)      // round 0 sees every hit; each later round is provisioned for 1/4 of the previous one
         round_items[r] = r == 0 ? (unsigned)band_samples : (unsigned)std::max<long long>(1024, (long long)round_items[r - 1] / 4);
@@ -410,6 +413,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.row_limit = std::min(fc.num_rows, (h + 1) * rows_half);
         P.persistent_blocks = s->num_cus * 8;
         P.per_lane_shadows = (f->flags & SR_F_PER_LANE_SHADOWS) != 0;
+        P.exact_shadow_tests = s->dbg[SR_DBG_EXACT_SHADOW_TESTS] > 0;
         P.stats = d_stats;
         P.stream = bs;
         P.user = s;
@@ -556,7 +560,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         s->bvh_on_device = true;
         s->bvh_dirty = false;
     } else if (modes & (1u << SR_MODE_BVH)) {
-        sr::build_bvh(s->v9, s->root, s->bvh);
+        sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(7, s->dbg[SR_DBG_BVH_LEAF]) : 4);
         if (s->bvh.depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
         s->bvh_on_device = false;
         s->bvh_dirty = true;
@@ -601,7 +605,7 @@ int sr_render_device(sr_scene* s, const sr_frame* f, void* d_pixels, void* hip_s
     if ((rc = check_mode(s, f->trace_mode))) return rc;
     if ((rc = use_device(s))) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
-    if (d_stats) SR_HIP(hipMemsetAsync(d_stats, 0, 12 * sizeof(uint64_t), stream));
+    if (d_stats) SR_HIP(hipMemsetAsync(d_stats, 0, 16 * sizeof(uint64_t), stream));
     return render_common(s, f, (uint32_t*)d_pixels, stream, (unsigned long long*)d_stats);
 }
 
@@ -615,8 +619,8 @@ int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]
     SR_HIP(s->d_pixels.reserve((size_t)count * 4));
     unsigned long long* d_stats = nullptr;
     if (stats) {
-        SR_HIP(s->d_stats.reserve(12 * sizeof(uint64_t)));
-        SR_HIP(hipMemsetAsync(s->d_stats.p, 0, 12 * sizeof(uint64_t), nullptr));
+        SR_HIP(s->d_stats.reserve(16 * sizeof(uint64_t)));
+        SR_HIP(hipMemsetAsync(s->d_stats.p, 0, 16 * sizeof(uint64_t), nullptr));
         d_stats = (unsigned long long*)s->d_stats.p;
     }
     if ((rc = render_common(s, f, (uint32_t*)s->d_pixels.p, nullptr, d_stats))) return rc;
@@ -632,7 +636,7 @@ int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]
         SR_HIP(hipMemcpy(pixels + off, (const int32_t*)s->d_pixels.p + off, n * 4, hipMemcpyDeviceToHost));
     }
     if (stats) {
-        SR_HIP(hipMemcpy(s->last_stats, s->d_stats.p, 12 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        SR_HIP(hipMemcpy(s->last_stats, s->d_stats.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
         std::memcpy(stats, s->last_stats, 4 * sizeof(uint64_t));
     }
     return SR_OK;
@@ -693,7 +697,7 @@ int sr_get_triangles(const sr_scene* s, double* v9, uint32_t* argb, double box_m
     return SR_OK;
 }
 
-int sr_last_ray_stats(const sr_scene* s, uint64_t out[12]) {
+int sr_last_ray_stats(const sr_scene* s, uint64_t out[16]) {
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
     std::memcpy(out, s->last_stats, sizeof(s->last_stats));
     return SR_OK;
@@ -783,6 +787,12 @@ int sr_debug_counters(sr_scene* s, uint32_t out[8]) {
     if (!s->scratch[0].counters.p) { for (int i = 0; i < 8; ++i) out[i] = 0; return SR_OK; }
     SR_HIP(hipDeviceSynchronize());
     SR_HIP(hipMemcpy(out, s->scratch[0].counters.p, 32, hipMemcpyDeviceToHost));   // first half of the frame
+    return SR_OK;
+}
+
+int sr_debug_set(sr_scene* s, int32_t key, int64_t value) {
+    if (!s || key < 0 || key >= SR_DBG_COUNT) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_debug_set");
+    s->dbg[key] = value;
     return SR_OK;
 }
 

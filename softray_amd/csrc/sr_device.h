@@ -79,6 +79,7 @@ struct PipelineLaunch {
     int32_t     row_first, row_limit; // compact rows [row_first, row_limit) of the frame are this launch's share
     int32_t     persistent_blocks;
     bool        per_lane_shadows; // force k_shadow (one lane per hit) instead of k_shadow_packet (cross-check)
+    bool        exact_shadow_tests; // k_shadow_test (every pair in FP64) instead of k_shadow_cls (fp32 classification first)
     unsigned long long* stats;  // device [8] or nullptr
     hipStream_t stream;
     void (*get_events)(void* user, int kernel_id, hipEvent_t* start, hipEvent_t* stop);   // optional per-launch timing

@@ -269,7 +269,7 @@ struct BvhBuilder {
     Bvh& out;
     const RootBox& root;
     double pad;
-    int kLeafMax = 4;                // triangles per leaf (SR_BVH_LEAF = 1..7 overrides: experiment hook, scripts/gpu_leaf.sh)
+    int kLeafMax = 4;                // triangles per leaf (sr_debug_set(SR_DBG_BVH_LEAF) = 1..7 overrides: experiment hook)
 
     float down(double v) const { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; }
     float up(double v) const { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; }
@@ -343,13 +343,13 @@ struct BvhBuilder {
 };
 }  // namespace
 
-void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out) {
+void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int leaf_max) {
     out = Bvh();
     size_t n = v9.size() / 9;
     double ext = 0;
     for (int a = 0; a < 3; ++a) ext = std::max(ext, root.max[a] - root.min[a]);
     BvhBuilder bb{{}, {}, out, root, std::ldexp(ext > 0 ? ext : 1.0, -16)};
-    if (const char* e = std::getenv("SR_BVH_LEAF")) bb.kLeafMax = std::min(7, std::max(1, std::atoi(e)));
+    bb.kLeafMax = std::min(7, std::max(1, leaf_max));
     bb.tb.resize(n);
     bb.cen.resize(n * 3);
     out.order.resize(n);

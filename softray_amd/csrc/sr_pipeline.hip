@@ -856,6 +856,301 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
 }
 
 // --------------------------------------------------------------------------------------------------
+// k_shadow_cls -- the default exact-test half of the shaft path: same items, same lists, same verdicts as k_shadow_test,
+// but a (sample, triangle) pair is first CLASSIFIED in fp32 with a rigorous error bound; only the pairs the bound cannot
+// decide (a crossing within ~1e-6 of a triangle edge, of the surface point, of the root box, or a grazing plane) run the
+// reference's FP64 arithmetic (prepare_sample + tri_blocks, exactly as in k_shadow_test).
+//
+// Geometry, parametrised from the surface end like the shaft: sample ray i is X(u) = E' + u D_i, D_i = (L - E') + off_i,
+// u in [0, 1] (u = 1 - rayFrac).  With the triangle's TriSlab planes (unit normals, root-centre-relative; the record
+// k_shaft filtered with): plane function G(x) = n.x - d, edge functions F_k(x) = m_k.x - c_k (>= 0 inside).  Along the
+// ray G = G0 + u g1_i with G0 = G(E'), g1_i = n.D_i, so the crossing is at u_c = -G0 / g1_i and there
+//     F_k = K0_k + u_c (m_k.D_i) = (w_k . D_i) / g1_i,      w_k = K0_k n - G0 m_k,  K0_k = F_k(E')
+// i.e. w_k is the normal of the plane through E' and edge k: the sample is inside the triangle's cone iff w_k.D_i >= 0
+// for k = 1..3 -- no division, and w_k depends on (hit point, triangle) only.  Triangle.IntersectRay (Triangle.cs:83-104)
+// + the tree's conditions (SpatialSubdivision.cs:394-401,652; ShadowMethod.cs:170) accept the crossing iff it is
+// front-facing (dirDist = -g1_i < 0), at or behind the clipped start, rayFrac + offset <= 1.0 (u_c >= 0 <=> G0 <= 0), inside
+// the root box and inside the three edges.
+//
+// Error bounds (u = 2^-24; every stored fp32 value is the rounding of its FP64 source; dot products are FMA chains):
+//   |G0 - true|, |K0_k - true| <= 5u (|E'|_2 + |d|)  <  a0 := 12u s0,   s0 = 2 (half diagonal of the root box + 0.002)
+//   |g1_i - true| <= 8u dmax  <  a1 := 20u dmax,   dmax = |L - E'|_2 + R;   "front-facing" needs g1_i >= glo := 16 a1
+//   |c_k - true w_k.D_i| <= dmax u (10 s0 + 11 (|K0_k| + |G0|))  <  mc := dmax u (15 s0 + 16 (max_k |K0_k| + |G0|)) + 1e-9 dmax
+//     (w_k inherits 2 a0' from G0 / K0_k and 3u (|K0_k| + |G0|) from its own rounding; the two-part dot product adds 8u |w_k| dmax)
+// FP64 evaluation errors (~1e-15) are six orders of magnitude below these margins, so with g1_i >= glo:
+//   BLOCKED  <=  G0 <= -a0 (u_c > 0)  and  min_k c_k > mc (inside every edge by > 1e-9)  and  G0 + umax_i g1_i > a0 + a1 (u_c < umax_i)
+//   MISS     <=  min_k c_k < -mc (outside an edge)  or  G0 >= a0 (crossing behind the surface point);   also g1_i <= -glo (back-facing)
+// umax_i <= 1 is a per-(hit point, sample) parameter at which X(u) is VERIFIED (position error bound pm) to lie inside the
+// root box; E' is verified too, so by convexity every crossing with u_c < umax_i lies inside the box and strictly in front
+// of the clipped start (SpatialSubdivision.cs:394).  Everything else is "uncertain" and decided by the FP64 code.  A
+// degenerate triangle's TriSlab is all zeros: g1 = 0, always uncertain.  With g1_i >= glo every intermediate is finite.
+// --------------------------------------------------------------------------------------------------
+constexpr float kU24 = 5.9604645e-8f;    // 2^-24
+constexpr int kClsCand = 32;             // candidates staged per chunk (5 float4 each): one bit each in a lane's "uncertain" masks
+
+struct ClsFrame {                         // per-frame fp32 constants of the classification
+    float cx, cy, cz, hbx, hby, hbz, s0, a0, R;
+};
+
+__device__ __forceinline__ ClsFrame cls_frame(const DevScene& sc, const FrameConst& fc) {
+    ClsFrame c;
+    c.cx = (float)sc.root.centre[0]; c.cy = (float)sc.root.centre[1]; c.cz = (float)sc.root.centre[2];
+    const float ex = (float)(sc.root.max[0] - sc.root.min[0]), ey = (float)(sc.root.max[1] - sc.root.min[1]), ez = (float)(sc.root.max[2] - sc.root.min[2]);
+    c.hbx = 0.5f * ex * 0.9999999f; c.hby = 0.5f * ey * 0.9999999f; c.hbz = 0.5f * ez * 0.9999999f;   // rounded towards the centre
+    c.s0 = (sqrtf(ex * ex + ey * ey + ez * ez) * 0.5f + 0.002f) * 2.002f;
+    c.a0 = 12.0f * kU24 * c.s0;
+    c.R = (float)fc.light_radius * 1.0001f + 1e-30f;
+    return c;
+}
+
+template <bool EXTRA, bool STATS>
+__global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
+                                                    const HitRec* __restrict__ hits, const unsigned int* __restrict__ hit_count,
+                                                    unsigned int count_cap, const unsigned int* __restrict__ index_list,
+                                                    const RoundState* __restrict__ state_in, int cap, int lists_by_hit,
+                                                    const unsigned int* __restrict__ cand_count, const int32_t* __restrict__ cand,
+                                                    unsigned int* __restrict__ next_count, unsigned int next_cap,
+                                                    unsigned int* __restrict__ next_list, RoundState* __restrict__ state_out,
+                                                    unsigned int* __restrict__ last_count, unsigned int* __restrict__ last_list,
+                                                    RoundState* __restrict__ last_state,
+                                                    uint32_t* __restrict__ samples, unsigned long long* stats) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    float4* wc = reinterpret_cast<float4*>(lds_pipe) + (size_t)wave * (kClsCand * 5 + kClsCand / 4);
+    int32_t* wrecidx = reinterpret_cast<int32_t*>(wc + kClsCand * 5);    // record position of every staged candidate
+    const int S = fc.shadow_samples;
+    const unsigned int total = min(*hit_count, count_cap);
+    const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
+    const ClsFrame cf = cls_frame(sc, fc);
+    D3 off[kPacketSlots];
+    bool valid[kPacketSlots];
+#pragma unroll
+    for (int k = 0; k < kPacketSlots; ++k) {
+        int j = lane + 64 * k;
+        valid[k] = j < S;
+        int jj = valid[k] ? j : 0;
+        off[k] = mk(offsets[3 * jj], offsets[3 * jj + 1], offsets[3 * jj + 2]);
+    }
+    const f2 OX = {(float)off[0].x, (float)off[1].x}, OY = {(float)off[0].y, (float)off[1].y}, OZ = {(float)off[0].z, (float)off[1].z};
+    uint32_t n_rays = 0, n_items = 0, n_recs = 0, n_cls = 0, n_exact = 0;
+    const unsigned int nwaves = gridDim.x * 4u;
+    const unsigned int s0 = blockIdx.x * 4u + (unsigned)wave;
+    // software pipeline over this wave's items: hit index two items ahead, hit record / list head one item ahead
+    unsigned int h_cur = 0, h_nxt = 0;
+    HitRec rec_cur;
+    unsigned int cc_cur = 0;
+    int32_t ent_cur = 0;
+    if (s0 < total) {
+        h_cur = index_list ? index_list[s0] : s0;
+        rec_cur = hits[h_cur];
+        const size_t li0 = lists_by_hit ? (size_t)h_cur : (size_t)s0;
+        cc_cur = cand_count[li0];
+        ent_cur = lane < cap ? cand[li0 * cap + lane] : 0;
+    }
+    if (s0 + nwaves < total) h_nxt = index_list ? index_list[s0 + nwaves] : s0 + nwaves;
+    for (unsigned int slot_i = s0; slot_i < total; slot_i += nwaves) {
+        const unsigned int h = h_cur;
+        const HitRec rec = rec_cur;
+        const unsigned int cc = cc_cur;
+        int32_t ent = ent_cur;
+        n_items++;
+        const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
+        const size_t li = lists_by_hit ? (size_t)h : (size_t)slot_i;   // round 0: lists are stored per hit, later rounds per item
+        const int ntri = (int)(cc & 0xffffu);
+        const bool truncated = (cc & kTruncated) != 0;
+        const int32_t* list = cand + li * cap;
+        const bool work = ntri > 0 || truncated;      // an empty, complete list: every sample escapes
+        // ---- this lane's candidate: the fp32 record k_shaft filtered with ----
+        TriSlab slab;
+        if (lane < ntri) slab = sc.bslab[ent];
+        uint32_t shaded = 0;
+        if (lane == 0 && !(fc.flags & 32u)) shaded = samples[rec.sample];
+        // ---- prefetch the next item ----
+        {
+            const unsigned int sn = slot_i + nwaves, snn = sn + nwaves;
+            h_cur = h_nxt;
+            if (sn < total) {
+                rec_cur = hits[h_cur];
+                const size_t lin = lists_by_hit ? (size_t)h_cur : (size_t)sn;
+                cc_cur = cand_count[lin];
+                ent_cur = lane < cap ? cand[lin * cap + lane] : 0;
+            }
+            if (snn < total) h_nxt = index_list ? index_list[snn] : snn;
+        }
+        // ---- per hit point: fp32 frame of the classification ----
+        const D3 DLd = lpos - E;
+        const float efx = (float)(E.x - sc.root.centre[0]), efy = (float)(E.y - sc.root.centre[1]), efz = (float)(E.z - sc.root.centre[2]);
+        const float dlx = (float)DLd.x, dly = (float)DLd.y, dlz = (float)DLd.z;
+        const float dmax = sqrtf(dlx * dlx + dly * dly + dlz * dlz) * 1.0001f + cf.R;
+        const float a1 = 20.0f * kU24 * dmax, glo = 16.0f * a1;
+        const float pm = 5e-7f * (cf.s0 + dmax);                        // position error bound of E' + u D_i in fp32 (>= 4u (|E'| + u |D|))
+        const bool ein = fabsf(efx) < cf.hbx - pm && fabsf(efy) < cf.hby - pm && fabsf(efz) < cf.hbz - pm;
+        // ---- per (hit point, sample): state + umax ----
+        bool alive[kPacketSlots], escaped[kPacketSlots];
+        float umax[kPacketSlots];
+#pragma unroll
+        for (int q = 0; q < kPacketSlots; ++q) {
+            alive[q] = false;
+            escaped[q] = valid[q];
+            if (state_in) {                                               // later round: resume from the saved masks
+                const RoundState stt = state_in[slot_i];
+                escaped[q] = ((stt.escaped[q] >> lane) & 1ull) != 0 && !(cc & kUmbraItem);
+                alive[q] = work && ((stt.alive[q] >> lane) & 1ull) != 0;
+            } else if (valid[q]) {
+                n_rays++;
+                bool blocked = false;
+                if (EXTRA) { Ctr cx = {0, 0, 0, 0}; const D3 rs = lpos + off[q]; blocked = extras_block<EXTRA>(sc, rs, E - rs, cx); }
+                if (blocked) escaped[q] = false;
+                else alive[q] = work;
+            }
+            const float ox = q ? OX.y : OX.x, oy = q ? OY.y : OY.x, oz = q ? OZ.y : OZ.x;
+            const float dx = dlx + ox, dy = dly + oy, dz = dlz + oz;
+            const float rx = slab_inv(dx), ry = slab_inv(dy), rz = slab_inv(dz);
+            float ue = (__builtin_copysignf(cf.hbx, dx) - efx) * rx, re = rx;
+            const float ty = (__builtin_copysignf(cf.hby, dy) - efy) * ry, tz = (__builtin_copysignf(cf.hbz, dz) - efz) * rz;
+            if (ty < ue) { ue = ty; re = ry; }
+            if (tz < ue) { ue = tz; re = rz; }
+            if (1.0f < ue) { ue = 1.0f; re = 1.0f; }
+            const float ut = ue - (3.0f * pm * fabsf(re) + 1e-5f * ue + 1e-7f);
+            const float px = __builtin_fmaf(ut, dx, efx), py = __builtin_fmaf(ut, dy, efy), pz = __builtin_fmaf(ut, dz, efz);
+            const bool ok = ein && ut > 0.0f && fabsf(px) < cf.hbx - pm && fabsf(py) < cf.hby - pm && fabsf(pz) < cf.hbz - pm;
+            umax[q] = ok ? ut : -1.0f;
+        }
+        const f2 UM = {umax[0], umax[1]};
+        const float hbm = cf.a0 + a1;
+        bool have = __any(alive[0] || alive[1]);
+        for (int base = 0; base < ntri && have; base += kClsCand) {
+            const int nc = min(kClsCand, ntri - base);
+            if (base > 0) {                                               // lists longer than one chunk
+                ent = lane < nc ? list[base + lane] : 0;
+                if (lane < nc) slab = sc.bslab[ent];
+            }
+            // ---- per (hit point, candidate) constants, lane = candidate: cone planes through E' and their margins ----
+            if (lane < nc) {
+                const f2 edx = {efx, dlx}, edy = {efy, dly}, edz = {efz, dlz};
+                const f2 cn = {-slab.d, 0.0f}, c1 = {-slab.c1, 0.0f}, c2 = {-slab.c2, 0.0f}, c3 = {-slab.c3, 0.0f};
+                const f2 N = pk_fma(splat(slab.n[0]), edx, pk_fma(splat(slab.n[1]), edy, pk_fma(splat(slab.n[2]), edz, cn)));    // (G0, n.(L - E'))
+                const f2 P = pk_fma(splat(slab.m1[0]), edx, pk_fma(splat(slab.m1[1]), edy, pk_fma(splat(slab.m1[2]), edz, c1)));  // (K0_1, .)
+                const f2 Q = pk_fma(splat(slab.m2[0]), edx, pk_fma(splat(slab.m2[1]), edy, pk_fma(splat(slab.m2[2]), edz, c2)));
+                const f2 T = pk_fma(splat(slab.m3[0]), edx, pk_fma(splat(slab.m3[1]), edy, pk_fma(splat(slab.m3[2]), edz, c3)));
+                const float G0 = N.x;
+                float4 W[3];
+                const float K0[3] = {P.x, Q.x, T.x};
+                const float* mm[3] = {slab.m1, slab.m2, slab.m3};
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const float wx = __builtin_fmaf(K0[e], slab.n[0], -(G0 * mm[e][0]));
+                    const float wy = __builtin_fmaf(K0[e], slab.n[1], -(G0 * mm[e][1]));
+                    const float wz = __builtin_fmaf(K0[e], slab.n[2], -(G0 * mm[e][2]));
+                    W[e] = make_float4(wx, wy, wz, __builtin_fmaf(wx, dlx, __builtin_fmaf(wy, dly, wz * dlz)));
+                }
+                const float kmax = fmaxf(fmaxf(fabsf(P.x), fabsf(Q.x)), fabsf(T.x));
+                const float mc = dmax * (kU24 * (15.0f * cf.s0 + 16.0f * (kmax + fabsf(G0))) + 1e-9f);
+                float4* w = wc + lane * 5;
+                w[0] = make_float4(slab.n[0], slab.n[1], slab.n[2], N.y);
+                w[1] = W[0]; w[2] = W[1]; w[3] = W[2];
+                // .y: margin of "inside every edge" (unreachable unless E' is definitely behind the plane);
+                // .z: margin of "outside an edge" (always reached when E' is definitely in front of the plane)
+                w[4] = make_float4(G0, G0 <= -cf.a0 ? mc : 1e30f, G0 >= cf.a0 ? -1e30f : mc, 0.0f);
+                wrecidx[lane] = ent;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            n_recs += (uint32_t)nc;
+            // ---- fp32 classification of every (sample, candidate) pair.  tblk > 0: BLOCKED; tall > 0: decided (BLOCKED or
+            //      MISS); bit k of unc[q]: pair (sample q, candidate k) is undecided.  bsum[q] > 0: some candidate blocked the
+            //      sample (dead samples keep running through the arithmetic: nothing they produce is looked at) ----
+            uint32_t unc[kPacketSlots] = {0u, 0u};
+            float bsum[kPacketSlots] = {-1.0f, -1.0f};
+            for (int k = 0; k < nc && have; ++k) {
+                const float4 A = wc[k * 5], B1 = wc[k * 5 + 1], B2 = wc[k * 5 + 2], B3 = wc[k * 5 + 3], F = wc[k * 5 + 4];
+                // packed over the lane's two samples (.x = sample lane, .y = sample lane + 64)
+                const f2 g1 = pk_fma(splat(A.x), OX, pk_fma(splat(A.y), OY, pk_fma(splat(A.z), OZ, splat(A.w))));
+                const f2 c1 = pk_fma(splat(B1.x), OX, pk_fma(splat(B1.y), OY, pk_fma(splat(B1.z), OZ, splat(B1.w))));
+                const f2 c2 = pk_fma(splat(B2.x), OX, pk_fma(splat(B2.y), OY, pk_fma(splat(B2.z), OZ, splat(B2.w))));
+                const f2 c3 = pk_fma(splat(B3.x), OX, pk_fma(splat(B3.y), OY, pk_fma(splat(B3.z), OZ, splat(B3.w))));
+                const f2 hb = pk_fma(UM, g1, splat(F.x));                 // G at u = umax_i: > 0 <=> the crossing comes earlier
+                const f2 cmin = {fminf(fminf(c1.x, c2.x), c3.x), fminf(fminf(c1.y, c2.y), c3.y)};
+                const f2 s3 = g1 - splat(glo), s1 = cmin - splat(F.y), s4 = hb - splat(hbm);
+                const f2 tm0 = splat(-F.z) - cmin, bfv = splat(-glo) - g1;
+#pragma unroll
+                for (int q = 0; q < kPacketSlots; ++q) {
+                    const float s3q = q ? s3.y : s3.x;
+                    const float tblk = fminf(fminf(q ? s1.y : s1.x, s3q), q ? s4.y : s4.x);
+                    const float tall = fmaxf(fmaxf(fminf(q ? tm0.y : tm0.x, s3q), q ? bfv.y : bfv.x), tblk);
+                    bsum[q] = fmaxf(bsum[q], tblk);
+                    unc[q] |= tall > 0.0f ? 0u : (1u << k);
+                }
+                if (STATS) n_cls += (alive[0] && !(bsum[0] > 0.0f) ? 1u : 0u) + (alive[1] && !(bsum[1] > 0.0f) ? 1u : 0u);
+                have = __any((alive[0] && !(bsum[0] > 0.0f)) || (alive[1] && !(bsum[1] > 0.0f)));
+            }
+#pragma unroll
+            for (int q = 0; q < kPacketSlots; ++q) {
+                if (alive[q] && bsum[q] > 0.0f) { alive[q] = false; escaped[q] = false; }
+            }
+            // ---- the undecided pairs of the samples no candidate blocked so far: the reference's FP64 arithmetic, one
+            //      copy of the code for both sample slots (rare: a few percent of the items have any) ----
+            if (__any((alive[0] && unc[0] != 0u) || (alive[1] && unc[1] != 0u))) {
+#pragma unroll 1
+                for (int q = 0; q < kPacketSlots; ++q) {
+                    uint32_t m = (q ? alive[1] : alive[0]) ? (q ? unc[1] : unc[0]) : 0u;
+                    if (m) {
+                        const D3 rs = lpos + (q ? off[1] : off[0]);
+                        SampleRay ray;
+                        bool is_alive = prepare_sample(sc, rs, E - rs, ray);  // false: the ray misses the root box, nothing can block it
+                        bool blocked = false;
+                        while (is_alive && m) {
+                            const int k = __ffs((int)m) - 1;
+                            m &= m - 1u;
+                            if (STATS) n_exact++;
+                            if (tri_blocks(sc.btris[wrecidx[k]].p, ray, sc.root.lo, sc.root.hi)) { is_alive = false; blocked = true; }
+                        }
+                        if (!is_alive) {
+                            if (q) { alive[1] = false; if (blocked) escaped[1] = false; }
+                            else { alive[0] = false; if (blocked) escaped[0] = false; }
+                        }
+                    }
+                }
+                have = __any(alive[0] || alive[1]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (have && truncated) {
+            // the list ran out before the shaft did and some sample is still undecided: next round, or the exact fallback
+            const unsigned long long a0m = __ballot(alive[0]), a1m = __ballot(alive[1]), e0 = __ballot(escaped[0]), e1m = __ballot(escaped[1]);
+            if (lane == 0) {
+                unsigned int slot = next_count ? atomicAdd(next_count, 1u) : 0xffffffffu;
+                RoundState o;
+                o.alive[0] = a0m; o.alive[1] = a1m; o.escaped[0] = e0; o.escaped[1] = e1m;
+                if (slot < next_cap) {
+                    next_list[slot] = h;
+                    state_out[slot] = o;
+                } else {
+                    const unsigned int fi = atomicAdd(last_count, 1u);    // the fallback only traces the undecided samples
+                    last_list[fi] = h;
+                    last_state[fi] = o;
+                }
+            }
+        } else {
+            const int esc = (int)__popcll(__ballot(escaped[0])) + (int)__popcll(__ballot(escaped[1]));
+            if (lane == 0) {
+                double frac = (double)esc / (double)S;                     // ShadowMethod.IntersectRay :113-119
+                finish_hit(sc, fc, samples, rec.sample, rec.pad[0], shaded, frac);
+            }
+        }
+    }
+    if (STATS) {
+        uint32_t a = wave_sum(n_rays), b = wave_sum(n_cls), c = wave_sum(n_exact);
+        if (lane == 0) {
+            stat_add(&stats[4], a); stat_add(&stats[5], b);
+            stat_add(&stats[8], n_recs);             // wave-level: fp32 triangle records read
+            stat_add(&stats[9], n_items);            // wave-level: hit points processed
+            stat_add(&stats[12], b); stat_add(&stats[13], c);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // Exact fallback of the shaft path: hit points whose candidate lists overflowed in every round still have undecided
 // samples (masks in RoundState).  Each undecided sample is one any-hit BVH walk.
 //   k_fb_expand    lane = fallback entry: appends one ray id (entry << 7 | sample) per undecided sample to a ray list
@@ -1470,7 +1765,12 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
             // round 0 iterates the compacted list of hits that k_shaft could not decide by itself
             const unsigned int* t_count = first ? work0 : count_ptr;
             const unsigned int* t_list = first ? L.round_list[0] : ilist;
-            if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
+            if (!L.exact_shadow_tests) {
+                // default: fp32 classification, FP64 only for the pairs it cannot decide
+                const size_t lds_c = 4 * ((size_t)kClsCand * 5 + kClsCand / 4) * sizeof(float4);
+                if (L.stats) hipLaunchKernelGGL((k_shadow_cls<EXTRA, true>), dim3(blocks), dim3(256), lds_c, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
+                else hipLaunchKernelGGL((k_shadow_cls<EXTRA, false>), dim3(blocks), dim3(256), lds_c, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
+            } else if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
             else hipLaunchKernelGGL((k_shadow_test<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }

@@ -125,9 +125,13 @@ class GpuScene:
 
     def ray_stats(self):
         """primary {rays, tests, nodes, leaves} + secondary {rays, tests, nodes, leaves} of the last render(stats=True)."""
-        out = np.zeros(12, dtype=np.uint64)
+        out = np.zeros(16, dtype=np.uint64)
         _check(_lib.lib().sr_last_ray_stats(self._h, _p(out)))
         return out
+
+    def debug_set(self, key, value):
+        """Test / experiment hook of this scene (include/softray.h SR_DBG_*); value < 0 restores the default."""
+        _check(_lib.lib().sr_debug_set(self._h, int(key), int(value)))
 
     def debug_counters(self):
         out = np.zeros(8, dtype=np.uint32)

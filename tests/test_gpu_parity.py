@@ -311,7 +311,7 @@ def test_shadow_sample_variants(obj_pair):
             assert np.array_equal(got, want), (count, mode)
 
 
-def test_pipeline_bands_rounds_and_fallback(monkeypatch):
+def test_pipeline_bands_rounds_and_fallback():
     """Force tiny row bands and tiny candidate lists so that a small frame goes through several bands, the second shaft
     round and the exact wave-per-hit fallback; the image must not change."""
     v9, argb, bmin, bmax = unit_cube_scene(20000)
@@ -323,22 +323,77 @@ def test_pipeline_bands_rounds_and_fallback(monkeypatch):
     want, _ = o.render(f, threads=NCPU)
     base, _ = g.render(as_sr(f, sa.MODE_BVH))
     assert np.array_equal(base, want)
-    monkeypatch.setenv("SR_BAND_SAMPLES", "2000")
-    monkeypatch.setenv("SR_ROUND_CAP0", "2")
-    monkeypatch.setenv("SR_ROUND_CAP1", "3")
+    g.debug_set(sa._lib.DBG_BAND_SAMPLES, 2000)
+    g.debug_set(sa._lib.DBG_ROUND_CAP0, 2)
+    g.debug_set(sa._lib.DBG_ROUND_CAP1, 3)
     got, _ = g.render(as_sr(f, sa.MODE_BVH))
     assert np.array_equal(got, want)
     c = g.debug_counters()
     assert c[2] > 0 and c[3] > 0, c            # round 2 and the fallback were really exercised
     # the fallback's ray list too small for most entries: they take the one-wave-per-hit kernel instead
-    monkeypatch.setenv("SR_FB_RAY_CAP", "40")
+    g.debug_set(sa._lib.DBG_FB_RAY_CAP, 40)
     got, _ = g.render(as_sr(f, sa.MODE_BVH))
     assert np.array_equal(got, want)
-    monkeypatch.delenv("SR_FB_RAY_CAP")
+    g.debug_set(sa._lib.DBG_FB_RAY_CAP, -1)
     f2 = make_frame(96, 80, depth=1.5, shadows=True, sub_pixel_res=2, focal_blur=True)
     want2, _ = o.render(f2, threads=NCPU)
     got2, _ = g.render(as_sr(f2, sa.MODE_BVH))
     assert np.array_equal(got2, want2)
+
+
+def test_fp32_classification_against_exact_schedule():
+    """k_shadow_cls (fp32 classification of (sample, triangle) pairs with a rigorous error bound, FP64 only for the pairs it
+    cannot decide) against k_shadow_test (every pair in FP64) and the oracle: a soup, a scene whose triangles touch the root
+    box faces and sit in a few planes (crossings exactly on edges / box faces: many undecidable pairs), a light inside the
+    root box, and extra geometry."""
+    # (a) soup
+    v9, argb, bmin, bmax = unit_cube_scene(40000)
+    # (b) axis-aligned quads split into triangles on a lattice, touching the box faces: shared edges, coplanar neighbours
+    q = []
+    n = 12
+    for i in range(n):
+        for j in range(n):
+            for z in (-0.5, -0.25, 0.0, 0.5):
+                x0, x1 = -0.5 + i / n, -0.5 + (i + 1) / n
+                y0, y1 = -0.5 + j / n, -0.5 + (j + 1) / n
+                if (i + j + int(z * 4)) % 3 == 0:
+                    continue
+                q.append([[x0, y0, z], [x1, y0, z], [x1, y1, z]])
+                q.append([[x0, y0, z], [x1, y1, z], [x0, y1, z]])
+                q.append([[x0, z, y0], [x1, z, y1], [x1, z, y0]])      # the same pattern in y = z planes, other winding
+    lattice = np.array(q, dtype=np.float64)
+    lat_argb = (0xFF000000 | (np.arange(len(lattice), dtype=np.uint64) * 2654435761 & 0xFFFFFF)).astype(np.uint32)
+    seen = [0, 0]
+    scenes = [("soup", v9, argb, {}), ("lattice", lattice, lat_argb, {}),
+              ("soup_light_inside", v9[:8000], argb[:8000], dict(light_inside=True))]
+    for name, tv, ta, opt in scenes:
+        g = sa.GpuScene(0); o = orc.Scene()
+        for s_ in (g, o):
+            s_.set_triangles(tv, ta, bmin, bmax)
+        g.build((sa.MODE_BVH,)); assert o.build_tree() == 0
+        for kw in (dict(), dict(yaw_deg=20.0, pitch_deg=35.0), dict(sub_pixel_res=2)):
+            f = make_frame(112, 96, depth=1.5, shadows=True, **kw)
+            if opt.get("light_inside"):
+                f.light_pos_view[0], f.light_pos_view[1], f.light_pos_view[2] = 0.05, 0.1, 1.45     # inside the unit cube at depth 1.5
+            want, _ = o.render(f, threads=NCPU)
+            g.debug_set(sa._lib.DBG_EXACT_SHADOW_TESTS, -1)
+            got, _ = g.render(as_sr(f, sa.MODE_BVH))
+            st = g.ray_stats()
+            assert np.array_equal(got, want), (name, kw)
+            if st[4] > 0:                                             # (k_shaft may decide every hit point of a frame by itself)
+                assert st[12] > 0 and st[13] < st[12], (name, st)     # pairs were classified in fp32, only a part needed FP64
+                seen[0] += int(st[12]); seen[1] += int(st[13])
+            g.debug_set(sa._lib.DBG_EXACT_SHADOW_TESTS, 1)
+            exact, _ = g.render(as_sr(f, sa.MODE_BVH))
+            assert np.array_equal(exact, want), (name, kw)
+            assert g.ray_stats()[12] == 0
+        if name == "soup":
+            prims = c1_spheres(5)
+            g.set_extra(prims); o.set_extra(prims)
+            f = make_frame(96, 80, depth=1.5, shadows=True)
+            g.debug_set(sa._lib.DBG_EXACT_SHADOW_TESTS, -1)
+            assert np.array_equal(g.render(as_sr(f, sa.MODE_BVH))[0], o.render(f, threads=NCPU)[0])
+    assert seen[0] > 1000000 and seen[1] > 0, seen                    # both the fp32 verdicts and the FP64 path were exercised
 
 
 def test_full_size_properties():
@@ -427,15 +482,14 @@ def test_reflection_extension_matches_oracle():
     assert np.array_equal(single, want)
     nosplit = as_sr(f, sa.MODE_BVH); nosplit.flags |= sa._lib.F_NO_SPLIT
     assert np.array_equal(g.render(nosplit)[0], want)
-    monkey_env = dict(os.environ)
-    os.environ["SR_BAND_SAMPLES"] = "3000"
+    g.debug_set(sa._lib.DBG_BAND_SAMPLES, 3000)
     try:
         assert np.array_equal(g.render(as_sr(f, sa.MODE_BVH))[0], want)
         f2 = make_frame(96, depth=1.5, sub_pixel_res=2)
         f2.max_bounces, f2.reflectivity = 3, 0.6
         assert np.array_equal(g.render(as_sr(f2, sa.MODE_BVH))[0], o.render(f2, threads=NCPU)[0])
     finally:
-        os.environ.clear(); os.environ.update(monkey_env)
+        g.debug_set(sa._lib.DBG_BAND_SAMPLES, -1)
     full = want.reshape(96, 96)
     for k in range(3):
         fs = make_frame(96, depth=1.5, strips=(8, 3, k))
