@@ -256,8 +256,8 @@ int  sr_anti_alias_device(sr_scene*, const void* d_src, int32_t dst_width, int32
  * schedule with the host's env.  value < 0 restores the default.  Used by tests/ and scripts/ only. */
 enum {
     SR_DBG_BAND_SAMPLES   = 0,   /* samples per row band (default 16 Mi / 32 Mi): small values force several bands             */
-    SR_DBG_ROUND_CAP0     = 1,   /* candidate-list length of shaft round 1 (<= 32)                                             */
-    SR_DBG_ROUND_CAP1     = 2,   /* ... of round 2 (<= 32): tiny lists force round 2 and the exact fallback                    */
+    SR_DBG_ROUND_CAP0     = 1,   /* candidate-list length of shaft round 1 (default 32, <= 64)                                 */
+    SR_DBG_ROUND_CAP1     = 2,   /* ... of round 2 (default 64, <= 64): tiny lists force round 2 and the exact fallback        */
     SR_DBG_SPLIT          = 3,   /* concurrent part-frame pipelines (default 2, <= 4)                                          */
     SR_DBG_FB_RAY_CAP     = 4,   /* capacity of the fallback ray list                                                          */
     SR_DBG_BVH_LEAF       = 5,   /* triangles per leaf of the host SAH build (default 4, 1..7); read by the next sr_build      */
@@ -265,6 +265,8 @@ enum {
     SR_DBG_KERNEL_TIMING  = 7,   /* > 0: record a HIP event pair around every launch (sr_kernel_times); default off           */
     SR_DBG_EXACT_SHADOW_TESTS = 8, /* > 0: k_shadow_test decides every (sample, triangle) pair with the FP64 arithmetic (no
                                     fp32 classification): an independent schedule of the same result, kept as a cross-check */
+    SR_DBG_PER_LANE_SHAFT = 9,   /* > 0: first shaft round with private per-lane walks (k_shaft) instead of the wave-cooperative
+                                    packet walk (k_shaft_pkt): same lists up to order, same pixels; cross-check                */
     SR_DBG_COUNT          = 16
 };
 int  sr_debug_set(sr_scene*, int32_t key, int64_t value);

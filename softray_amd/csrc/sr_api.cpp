@@ -312,8 +312,8 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     for (int r = 0; r < sr::kShaftRounds; ++r) round_cap[r] = sr::pipeline_round_cap(r);
     {   // test hooks (sr_debug_set): shrink the bands / candidate lists so that small frames exercise banding, round 2 and the fallback
         if (s->dbg[SR_DBG_BAND_SAMPLES] > 0) kMaxBandSamples = s->dbg[SR_DBG_BAND_SAMPLES];
-        if (s->dbg[SR_DBG_ROUND_CAP0] > 0) round_cap[0] = (int)std::min<int64_t>(s->dbg[SR_DBG_ROUND_CAP0], sr::pipeline_round_cap(0));
-        if (s->dbg[SR_DBG_ROUND_CAP1] > 0) round_cap[1] = (int)std::min<int64_t>(s->dbg[SR_DBG_ROUND_CAP1], sr::pipeline_round_cap(1));
+        if (s->dbg[SR_DBG_ROUND_CAP0] > 0) round_cap[0] = (int)std::min<int64_t>(s->dbg[SR_DBG_ROUND_CAP0], sr::pipeline_round_cap_max(0));
+        if (s->dbg[SR_DBG_ROUND_CAP1] > 0) round_cap[1] = (int)std::min<int64_t>(s->dbg[SR_DBG_ROUND_CAP1], sr::pipeline_round_cap_max(1));
     }
     // Two halves of the frame (16-row granularity) run as two pipelines on two internal streams, each with its own scratch
     // set; a half that exceeds its share of the band budget is processed in sequential bands on its stream.  A static
@@ -324,9 +324,12 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     const int halves = split ? want_split : 1;
     const int rows_half = split ? (int)((((long long)fc.num_rows + halves - 1) / halves + 15) / 16 * 16) : fc.num_rows;
     const long long budget = kMaxBandSamples / halves;
-    long long band_rows = std::max<long long>(16, (budget / ((long long)fc.width * n2)) / 16 * 16);
+    // queue capacity counts whole 16x16-pixel tiles: the tile-aligned hit queue of the shaft path gives every wave (8x8 pixels
+    // x one sub-sample) 64 entries, also at the right / bottom edge of the frame
+    const long long wpad = ((long long)fc.width + 15) / 16 * 16;
+    long long band_rows = std::max<long long>(16, (budget / (wpad * n2)) / 16 * 16);
     band_rows = std::min<long long>(band_rows, ((long long)rows_half + 15) / 16 * 16);
-    const long long band_samples = band_rows * fc.width * n2;
+    const long long band_samples = band_rows * wpad * n2;
     if (static_shadows) {
         if (band_rows < fc.num_rows) return fail(SR_ERR_UNSUPPORTED, "static shadows: the frame does not fit one row band");
         SR_HIP(s->d_static_hits.reserve((size_t)std::min<long long>(band_samples, (long long)sr::pipeline_static_cells()) * sr::pipeline_hit_record_bytes()));
@@ -365,7 +368,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             SR_HIP(B.fallback_ovf.reserve((size_t)band_samples * 4));
             for (int r = 0; r < sr::kShaftRounds; ++r) {
                 SR_HIP(B.rcount[r].reserve((size_t)round_items[r] * 4));
-                SR_HIP(B.rcand[r].reserve((size_t)round_items[r] * sr::pipeline_round_cap(r) * 4));
+                SR_HIP(B.rcand[r].reserve((size_t)round_items[r] * round_cap[r] * 4));
                 SR_HIP(B.rlist[r].reserve((size_t)round_items[r] * 4));     // round 0: the hits k_shaft left undecided
                 if (r > 0) SR_HIP(B.rstate[r].reserve((size_t)round_items[r] * sr::pipeline_round_state_bytes()));
             }
@@ -414,6 +417,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.persistent_blocks = s->num_cus * 8;
         P.per_lane_shadows = (f->flags & SR_F_PER_LANE_SHADOWS) != 0;
         P.exact_shadow_tests = s->dbg[SR_DBG_EXACT_SHADOW_TESTS] > 0;
+        P.per_lane_shaft = s->dbg[SR_DBG_PER_LANE_SHAFT] > 0;
         P.stats = d_stats;
         P.stream = bs;
         P.user = s;

@@ -79,6 +79,7 @@ struct PipelineLaunch {
     int32_t     row_first, row_limit; // compact rows [row_first, row_limit) of the frame are this launch's share
     int32_t     persistent_blocks;
     bool        per_lane_shadows; // force k_shadow (one lane per hit) instead of k_shadow_packet (cross-check)
+    bool        per_lane_shaft;   // k_shaft (private walks) also for the first round instead of k_shaft_pkt (cross-check)
     bool        exact_shadow_tests; // k_shadow_test (every pair in FP64) instead of k_shadow_cls (fp32 classification first)
     unsigned long long* stats;  // device [8] or nullptr
     hipStream_t stream;
@@ -89,6 +90,7 @@ hipError_t launch_pipeline(const PipelineLaunch& L);
 size_t pipeline_hit_record_bytes();
 size_t pipeline_static_cells();
 int pipeline_round_cap(int round);
+int pipeline_round_cap_max(int round);
 size_t pipeline_round_state_bytes();
 
 // Own BVH built on the device (sr_lbvh.hip).  Inputs in TriangleIndex order, outputs caller-allocated (n entries each).

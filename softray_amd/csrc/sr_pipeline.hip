@@ -27,6 +27,7 @@ struct alignas(16) HitRec {
     uint32_t pad[3];     // pad[0]: cell of the static shadow cache (generator hits of a static frame)
 };
 static_assert(sizeof(HitRec) == 64, "HitRec must be 64 bytes");
+constexpr uint32_t kInvalidHit = 0xffffffffu;      // HitRec.sample of a padding entry of the tile-aligned hit queue
 
 // ShadowMethod.IntersectRay's last step for one surface point (ShadowMethod.cs:103-119): dynamic shadows modulate the
 // shaded colour with (byte)(fraction * 255); a static frame (SR_F_STATIC_SHADOWS) runs the shadow kernels only on the
@@ -55,7 +56,7 @@ template <int MODE, bool EXTRA, bool STATS, bool SUB>
 __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
                                                  int row_count, uint32_t* __restrict__ samples, HitRec* __restrict__ hits,
                                                  unsigned int* __restrict__ hit_count, uint32_t* __restrict__ bounce_levels,
-                                                 uint8_t* __restrict__ bounce_nlev, unsigned long long* stats) {
+                                                 uint8_t* __restrict__ bounce_nlev, unsigned long long* stats, int pad_tiles) {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup
@@ -128,10 +129,13 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
         if (shadows || bounce) {                                             // active-ray compaction
             unsigned long long m = __ballot(ok);
             if (m) {
+                // pad_tiles (shaft path): every wave with a hit takes 64 consecutive queue entries, lane = entry, lanes without
+                // a hit mark theirs invalid -- a wave of k_shaft_pkt then owns exactly one 8x8-pixel tile of surface points
                 unsigned int base = 0;
                 const int leader = __ffsll((long long)m) - 1;
-                if (lane == leader) base = atomicAdd(hit_count, (unsigned int)__popcll(m));
+                if (lane == leader) base = atomicAdd(hit_count, pad_tiles ? 64u : (unsigned int)__popcll(m));
                 base = __shfl(base, leader, 64);
+                if (pad_tiles && !ok) hits[base + (unsigned int)lane].sample = kInvalidHit;
                 if (ok) {
                     HitRec r;
                     r.pos[0] = h.pos.x; r.pos[1] = h.pos.y; r.pos[2] = h.pos.z;
@@ -145,7 +149,7 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
                         r.nrm[0] = refl.x; r.nrm[1] = refl.y; r.nrm[2] = refl.z;
                         r.pad[0] = 1u;
                     }
-                    hits[base + (unsigned int)__popcll(m & lanemask_lt())] = r;
+                    hits[base + (pad_tiles ? (unsigned int)lane : (unsigned int)__popcll(m & lanemask_lt()))] = r;
                 }
             }
         }
@@ -342,7 +346,7 @@ __device__ __forceinline__ bool tri_blocks(const double* p, const SampleRay& r, 
 constexpr int kPacketSlots = 2;          // samples per lane in k_shadow_test: S <= 128
 constexpr int kShaftCap = 32;            // triangles per candidate list in the first round (every hit)
 // later rounds only see the hits whose earlier candidates left samples undecided: longer lists, fewer hits
-constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 32};
+constexpr int kRoundCap[kShaftRounds] = {kShaftCap, 64};   // round 2 starts from scratch: room for round 1's candidates and as many new ones
 constexpr int kRecordsPerPass = 16;      // records staged through LDS per pass (2 KB per wave)
 // LDS strides (bank = address / 4 mod 64): in the (sample x candidate) layout the lanes of a wave read up to 8 different
 // records and up to 64 different rays at once; 144-byte records and 80-byte rays spread those over the banks
@@ -453,9 +457,15 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
     const unsigned int total = min(*hit_count, count_cap);
     const unsigned int slot_i = blockIdx.x * 256u + (unsigned)tid;       // list slot: the hit itself, or an entry of index_list
     uint32_t nodes = 0, leaves = 0, slabs = 0;
-    if (slot_i < total) {
-        const unsigned int h = index_list ? index_list[slot_i] : slot_i;
-        const HitRec rec = hits[h];
+    bool live = slot_i < total;
+    unsigned int h = 0;
+    HitRec rec;
+    if (live) {
+        h = index_list ? index_list[slot_i] : slot_i;
+        rec = hits[h];
+        live = rec.sample != kInvalidHit;                                  // padding entry of the tile-aligned queue
+    }
+    if (live) {
         const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
         const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;   // ShadowMethod.cs:151
         const float R = (float)fc.light_radius * 1.00001f + 1e-30f;
@@ -562,8 +572,144 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         }
     }
     if (STATS) {
-        uint32_t a = wave_sum(nodes), b = wave_sum(leaves), c2 = wave_sum(slabs), d2 = wave_sum(slot_i < total ? 1u : 0u);
+        uint32_t a = wave_sum(nodes), b = wave_sum(leaves), c2 = wave_sum(slabs), d2 = wave_sum(live ? 1u : 0u);
         block_stat_add(&stats[6], &stats[7], &stats[10], &stats[11], a, b, c2, d2);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_shaft_pkt -- the first shaft round as a wave-cooperative PACKET walk.  A wave owns 64 consecutive entries of the
+// tile-aligned hit queue = the surface points of one 8x8-pixel tile, whose shafts all end in the same light and start
+// within a few thousandths of each other: their walks visit nearly the same nodes.  So the wave walks the BVH ONCE --
+// one shared stack (LDS, wave-uniform), node and TriSlab records fetched with scalar loads, near child first by a vote of
+// the interested lanes -- and every lane tests its OWN shaft against the broadcast boxes / triangles, keeping its own
+// u-bound per stacked subtree (-1: the lane's shaft misses it).  A lane drops out when its list is full or it found an
+// umbra triangle; the walk ends when no live lane wants anything that is left.  Per-lane arithmetic and results are those
+// of k_shaft; only the ORDER in which a lane meets its candidates differs (it is the wave's), which is why the second round
+// re-collects from scratch instead of skipping "the first cap candidates" (launch_shadow_t).
+// k_shaft kept 19 of 64 lanes busy on average (neighbouring lanes are in different phases of their private loops);
+// here all lanes are at the same node at the same time.
+// --------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_shaft_pkt(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
+                                                   const unsigned int* __restrict__ hit_count, int cap, int levels,
+                                                   unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
+                                                   uint32_t* __restrict__ samples, unsigned int* __restrict__ work_count,
+                                                   unsigned int* __restrict__ work_list, unsigned long long* stats) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int32_t* wnode = reinterpret_cast<int32_t*>(lds_pipe) + (size_t)wave * ((size_t)levels * 65);   // [levels] stacked node
+    float* wbound = reinterpret_cast<float*>(wnode + levels) + lane;                               // [levels][64] per-lane u bound
+    const unsigned int total = *hit_count;
+    const unsigned int slot_i = blockIdx.x * 256u + (unsigned)tid;
+    HitRec rec;
+    rec.sample = kInvalidHit;
+    if (slot_i < total) rec = hits[slot_i];
+    const bool valid = rec.sample != kInvalidHit;
+    uint32_t nodes = 0, leaves = 0, slabs = 0;                    // wave-level (uniform)
+    const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
+    const D3 E = valid ? mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001 : lpos * 0.5;   // ShadowMethod.cs:151
+    const float R = (float)fc.light_radius * 1.00001f + 1e-30f;
+    float ext = 0.0f;
+    for (int a = 0; a < 3; ++a) ext = fmaxf(ext, (float)(sc.root.max[a] - sc.root.min[a]));
+    const float pad = ext * 3.0517578125e-5f;                          // 2^-15 * extent (boxes carry 2^-16 already)
+    const float pad_tri = ext * 7.62939453125e-6f;                     // 2^-17 * extent
+    const float ex = (float)(E.x - sc.root.centre[0]), ey = (float)(E.y - sc.root.centre[1]), ez = (float)(E.z - sc.root.centre[2]);
+    const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
+    const float ix = slab_inv(dx), iy = slab_inv(dy), iz = slab_inv(dz);
+    const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
+    const f2 OI01 = {-ex * ix, -ey * iy}, OI20 = {-ez * iz, -ex * ix}, OI12 = {-ey * iy, -ez * iz};
+    const f2 RI01 = {-ix, -iy}, RI20 = {-iz, ix}, RI12 = {iy, iz};
+    const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
+    ShaftRay sr;
+    sr.edx = (f2){ex, dx}; sr.edy = (f2){ey, dy}; sr.edz = (f2){ez, dz};
+    sr.R = R; sr.pad = pad_tri; sr.ext = ext;
+    sr.backface = R * 1.001f + 1e-6f * (fabsf(dx) + fabsf(dy) + fabsf(dz)) + 1e-30f;
+    sr.hbx = 0.5f * (float)(sc.root.max[0] - sc.root.min[0]); sr.hby = 0.5f * (float)(sc.root.max[1] - sc.root.min[1]); sr.hbz = 0.5f * (float)(sc.root.max[2] - sc.root.min[2]);
+    int32_t* out = cand + (size_t)slot_i * cap;
+    int count = 0;
+    bool truncated = false, umbra = false;
+    bool done = !valid;
+    int sp = 0;                      // wave-uniform
+    int32_t ni = 0;                  // wave-uniform: current inner node
+    float nu = valid ? 1.0f : -1.0f; // this lane's u bound inside the current subtree; < 0: the lane's shaft misses it
+    for (;;) {
+        if (__ballot(!done && nu >= 0.0f) == 0ull) {
+            // nobody wants the current subtree: pop until a live lane wants one
+            bool found = false;
+            while (sp > 0) {
+                --sp;
+                const float bu = wbound[sp * 64];
+                if (__ballot(!done && bu >= 0.0f) != 0ull) { ni = __builtin_amdgcn_readfirstlane(wnode[sp]); nu = bu; found = true; break; }
+            }
+            if (!found) break;
+        }
+        const BvhNode n = sc.bnodes[ni];                               // wave-uniform address: scalar loads
+        nodes++;
+        const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
+        const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
+        float a0, b0, a1, b1;                                          // child u-intervals [a, b] of this lane's shaft
+        node_slabs(n, I01, I20, I12, B0, B1, B2, a0, b0, a1, b1);
+        a0 = fmaxf(a0, umin); a1 = fmaxf(a1, umin);
+        b0 = fminf(b0, nu); b1 = fminf(b1, nu);
+        const bool h0 = !done && n.n0 >= 0 && a0 <= b0, h1 = !done && n.n1 >= 0 && a1 <= b1;
+        // the child nearest to the surface points first: vote of the lanes that touch both (a lane with one child has no opinion)
+        const bool first0 = __popcll(__ballot(h0 && h1 && a0 <= a1)) >= __popcll(__ballot(h0 && h1 && a1 < a0));
+        // ---- leaf children: every interested lane filters the (broadcast) triangles with its own shaft ----
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bool c0 = (t == 0) == first0;
+            const int cn = c0 ? n.n0 : n.n1, cc = c0 ? n.c0 : n.c1;
+            if (cn > 0 && __ballot((c0 ? h0 : h1) && !done) != 0ull) {
+                const float ua = c0 ? a0 : a1, ub = c0 ? b0 : b1;
+                const bool hc = c0 ? h0 : h1;
+                leaves++;
+                slabs += (uint32_t)cn;
+                for (int q = 0; q < cn; ++q) {
+                    const TriSlab s = sc.bslab[cc + q];               // scalar load
+                    if (hc && !done) {
+                        const int touch = shaft_touches(s, sr, ua, ub);
+                        if (touch == 2) umbra = true;
+                        if (touch) {
+                            if (count < cap) { out[count] = cc + q; count++; }
+                            else truncated = true;
+                        }
+                        done = umbra || truncated;
+                    }
+                }
+            }
+        }
+        // ---- inner children ----
+        const bool w0 = h0 && !done && n.n0 == 0, w1 = h1 && !done && n.n1 == 0;
+        const bool any0 = __ballot(w0) != 0ull, any1 = __ballot(w1) != 0ull;
+        if (any0 && any1) {
+            const int32_t far_node = first0 ? n.c1 : n.c0;
+            wnode[sp] = far_node;
+            wbound[sp * 64] = first0 ? (w1 ? b1 : -1.0f) : (w0 ? b0 : -1.0f);
+            sp++;
+            ni = first0 ? n.c0 : n.c1;
+            nu = first0 ? (w0 ? b0 : -1.0f) : (w1 ? b1 : -1.0f);
+        } else if (any0) { ni = n.c0; nu = w0 ? b0 : -1.0f; }
+        else if (any1) { ni = n.c1; nu = w1 ? b1 : -1.0f; }
+        else nu = -1.0f;                                               // leaf-only / dead end: pop at the top of the loop
+    }
+    if (valid) {
+        if (umbra) {
+            // fully shadowed: rayEscapeCount = 0 -> (byte)(0.0 * 255) = 0 -> ModulatePackedColor(color, 0) = opaque black
+            finish_hit(sc, fc, samples, rec.sample, rec.pad[0], (fc.flags & 32u) ? 0u : samples[rec.sample], 0.0);
+            cand_count[slot_i] = 0u;
+        } else if (count == 0 && !truncated && sc.nextra == 0) {
+            // nothing in the whole shaft and no extra geometry: every sample escapes (ShadowMethod.cs:113-119)
+            finish_hit(sc, fc, samples, rec.sample, rec.pad[0], (fc.flags & 32u) ? 0u : samples[rec.sample], (double)fc.shadow_samples / (double)fc.shadow_samples);
+            cand_count[slot_i] = 0u;
+        } else {
+            cand_count[slot_i] = (unsigned)count | (truncated ? kTruncated : 0u);
+            work_list[atomicAdd(work_count, 1u)] = slot_i;             // the compiler aggregates this per wavefront
+        }
+    }
+    if (STATS) {
+        const uint32_t d2 = wave_sum(valid ? 1u : 0u);
+        block_stat_add(&stats[6], &stats[7], &stats[10], &stats[11], nodes, leaves, slabs, d2);
     }
 }
 
@@ -1674,7 +1820,7 @@ static int pipe_stack_levels(const DevScene& sc, int mode) {
 }
 
 template <int MODE, bool EXTRA, bool SUB>
-static hipError_t launch_primary_s(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples) {
+static hipError_t launch_primary_s(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples, int pad_tiles) {
     // 1-D grid over the padded super-tile grid (see the tile order in k_primary)
     const int tiles_x = (L.fc.width + 15) / 16, tiles_y = (row_count + 15) / 16;
     const int spx = (((tiles_x + 7) / 8) + 7) / 8, sny = (tiles_y + 7) / 8;
@@ -1682,10 +1828,10 @@ static hipError_t launch_primary_s(const PipelineLaunch& L, int row_begin, int r
     size_t lds = (size_t)pipe_stack_levels(L.sc, MODE) * 256 * 4;
     if (L.stats)
         hipLaunchKernelGGL((k_primary<MODE, EXTRA, true, SUB>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
-                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats);
+                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats, pad_tiles);
     else
         hipLaunchKernelGGL((k_primary<MODE, EXTRA, false, SUB>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
-                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats);
+                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats, pad_tiles);
     return hipGetLastError();
 }
 
@@ -1711,12 +1857,17 @@ static void pipe_events(const PipelineLaunch& L, int kid, hipEvent_t& e0, hipEve
     if (L.get_events) L.get_events(L.user, kid, &e0, &e1);
 }
 
+template <int MODE>
+static bool shaft_path(const PipelineLaunch& L) {
+    return MODE == MODE_BVH && (L.fc.flags & 8u) && L.fc.shadow_samples <= 64 * kPacketSlots && !L.per_lane_shadows && L.round_cand[0];
+}
+
 // counters: [0] hit_count  [1] k_shadow work head  [2] fallback_count  [3] fallback work head
 template <int MODE, bool EXTRA>
 static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, long long max_hits) {
     hipError_t e;
     hipEvent_t e0, e1;
-    const bool shaft = MODE == MODE_BVH && (L.fc.flags & 8u) && L.fc.shadow_samples <= 64 * kPacketSlots && !L.per_lane_shadows && L.round_cand[0];
+    const bool shaft = shaft_path<MODE>(L);
     if (!shaft) {
         pipe_events(L, K_SHADOW, e0, e1);
         if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
@@ -1728,7 +1879,6 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
     // counters: [0] hits  [1] k_shadow head  [2..] items entering round 1, 2, ..  [2+R-1] fallback count  [6] round-0 work items
     unsigned int* fb_count = L.counters + 2 + (kShaftRounds - 1);
     unsigned int* work0 = L.counters + 6;
-    int skip = 0;
     for (int round = 0; round < kShaftRounds; ++round) {
         const bool first = round == 0, last = round == kShaftRounds - 1;
         const unsigned int* count_ptr = first ? L.counters : L.counters + 1 + round;
@@ -1741,12 +1891,23 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         pipe_events(L, first ? K_SHAFT : K_SHAFT2, e0, e1);
         if (e0 && (e = hipEventRecord(e0, L.stream)) != hipSuccess) return e;
         {
-            size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
+            const int levels = pipe_stack_levels(L.sc, MODE_BVH);
             unsigned blocks = (unsigned)((max_items + 255) / 256);
-            unsigned int* wc = first ? work0 : nullptr;
-            unsigned int* wl = first ? L.round_list[0] : nullptr;
-            if (L.stats) hipLaunchKernelGGL((k_shaft<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, L.round_cand_count[round], L.round_cand[round], samples, wc, wl, L.stats, L.counters);
-            else hipLaunchKernelGGL((k_shaft<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, skip, cap, L.round_cand_count[round], L.round_cand[round], samples, wc, wl, L.stats, L.counters);
+            if (first && !L.per_lane_shaft) {
+                // round 1: one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
+                size_t lds = (size_t)levels * 65 * 4 * 4;
+                if (L.stats) hipLaunchKernelGGL((k_shaft_pkt<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, levels, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
+                else hipLaunchKernelGGL((k_shaft_pkt<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, levels, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
+            } else {
+                // later rounds (scattered hit points: private walks).  They collect from scratch (skip = 0): the order in which
+                // round 1 met a hit point's candidates was its wave's, not this walk's, so "skip the first cap" would not name
+                // the same triangles; re-testing a candidate is harmless (it did not block the samples that are still undecided)
+                size_t lds = (size_t)levels * 256 * 4;
+                unsigned int* wc = first ? work0 : nullptr;
+                unsigned int* wl = first ? L.round_list[0] : nullptr;
+                if (L.stats) hipLaunchKernelGGL((k_shaft<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, 0, cap, L.round_cand_count[round], L.round_cand[round], samples, wc, wl, L.stats, L.counters);
+                else hipLaunchKernelGGL((k_shaft<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, 0, cap, L.round_cand_count[round], L.round_cand[round], samples, wc, wl, L.stats, L.counters);
+            }
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
@@ -1775,7 +1936,6 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
-        skip += cap;
     }
     // ---- fallback: hits that are still undecided after the longest list ----
     pipe_events(L, K_FALLBACK, e0, e1);
@@ -1821,8 +1981,10 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (L.get_events) L.get_events(L.user, K_PRIMARY, &e0, &e1);
         if (e0) { e = hipEventRecord(e0, L.stream); if (e != hipSuccess) return e; }
-        e = L.fc.sub_pixel_res > 1 ? launch_primary_s<MODE, EXTRA, true>(L, row_begin, row_count, samples)
-                                   : launch_primary_s<MODE, EXTRA, false>(L, row_begin, row_count, samples);
+        // the shaft path of a dynamic-shadow frame reads the hit queue tile by tile (k_shaft_pkt): 64-aligned entries
+        const int pad_tiles = (shadows && !(L.fc.flags & 32u) && L.fc.max_bounces == 0 && shaft_path<MODE>(L)) ? 1 : 0;
+        e = L.fc.sub_pixel_res > 1 ? launch_primary_s<MODE, EXTRA, true>(L, row_begin, row_count, samples, pad_tiles)
+                                   : launch_primary_s<MODE, EXTRA, false>(L, row_begin, row_count, samples, pad_tiles);
         if (e != hipSuccess) return e;
         if (e1) { e = hipEventRecord(e1, L.stream); if (e != hipSuccess) return e; }
         if (L.fc.max_bounces > 0 && L.bounce_levels) {
@@ -1872,7 +2034,8 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
             hipLaunchKernelGGL(k_static_apply, dim3(blocks), dim3(256), 0, L.stream, (const uint8_t*)L.sc.shadow_cache, (const HitRec*)L.hits, L.counters + 14, samples);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         } else if (shadows) {
-            e = launch_shadow_t<MODE, EXTRA>(L, samples, (long long)row_count * L.fc.width * n2);
+            // (queue entries are counted in whole tiles: see pad_tiles)
+            e = launch_shadow_t<MODE, EXTRA>(L, samples, (long long)((row_count + 15) / 16 * 16) * ((L.fc.width + 15) / 16 * 16) * n2);
             if (e != hipSuccess) return e;
         }
         if (n2 > 1) {
@@ -1903,6 +2066,7 @@ hipError_t launch_pipeline(const PipelineLaunch& L) {
 size_t pipeline_hit_record_bytes() { return sizeof(HitRec); }
 size_t pipeline_static_cells() { return (size_t)kStaticRes * kStaticRes * kStaticRes; }
 int pipeline_round_cap(int round) { return kRoundCap[round]; }   // default list length of a round
+int pipeline_round_cap_max(int) { return 64; }                   // longest list the kernels handle (sr_debug_set hooks)
 size_t pipeline_round_state_bytes() { return sizeof(RoundState); }
 
 }  // namespace sr

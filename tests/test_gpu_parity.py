@@ -396,6 +396,28 @@ def test_fp32_classification_against_exact_schedule():
     assert seen[0] > 1000000 and seen[1] > 0, seen                    # both the fp32 verdicts and the FP64 path were exercised
 
 
+def test_packet_shaft_walk_against_private_walks():
+    """k_shaft_pkt (one wave-cooperative walk per 8x8-pixel tile of surface points, tile-aligned hit queue) against k_shaft
+    (one private walk per lane) and the oracle: tiles that straddle the silhouette, odd frame sizes (partial tiles), sub-pixel
+    sampling (several queue tiles per pixel tile), tiny lists (round 2 re-collects from scratch, then the fallback)."""
+    v9, argb, bmin, bmax = unit_cube_scene(30000)
+    g = sa.GpuScene(0); o = orc.Scene()
+    for s_ in (g, o):
+        s_.set_triangles(v9, argb, bmin, bmax)
+    g.build((sa.MODE_BVH,)); assert o.build_tree() == 0
+    for kw in (dict(), dict(sub_pixel_res=2), dict(yaw_deg=10.0, pitch_deg=80.0), dict(start_row=5, end_row=70)):
+        f = make_frame(117, 91, depth=1.5, shadows=True, **kw)
+        want, _ = o.render(f, threads=NCPU)
+        for caps in (None, (2, 3), (5, 64)):
+            g.debug_set(sa._lib.DBG_ROUND_CAP0, caps[0] if caps else -1)
+            g.debug_set(sa._lib.DBG_ROUND_CAP1, caps[1] if caps else -1)
+            for per_lane in (0, 1):
+                g.debug_set(sa._lib.DBG_PER_LANE_SHAFT, per_lane)
+                got, _ = g.render(as_sr(f, sa.MODE_BVH))
+                assert np.array_equal(got, want), (kw, caps, per_lane)
+    g.debug_set(sa._lib.DBG_PER_LANE_SHAFT, -1)
+
+
 def test_full_size_properties():
     """BASELINE-size checks (1 M triangles, up to 4096^2) through size-independent properties: the three shadow schedules
     agree, the union of interleaved strips is the frame, rendering is idempotent, the own BVH and the literal reference
