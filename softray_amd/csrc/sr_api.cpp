@@ -73,7 +73,9 @@ struct sr_scene {
     bool        bvh_on_device = false;   // built by sr_lbvh.hip: no host copy of the nodes
     size_t      bvh_num_nodes = 0;
     // device state
-    DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab;
+    DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab, d_v9, d_bcam;
+    double cam_origin[3] = {0, 0, 0};    // ray origin the camera-cone records in d_bcam were made for
+    bool   cam_valid = false;
     DBuf d_shadow_cache, d_static_claim, d_static_hits;
     bool shadow_cache_empty = true;      // the device cache must be zeroed before its next use
     DBuf d_offsets, d_rowmap, d_pixels, d_aa, d_stats, d_io[9];
@@ -116,7 +118,7 @@ int use_device(sr_scene* s) {
 }
 
 int sync_geometry(sr_scene* s, uint32_t need_mode) {
-    if (s->tris_dirty) { SR_HIP(s->d_tris.upload(s->tri_recs)); s->tris_dirty = false; }
+    if (s->tris_dirty) { SR_HIP(s->d_tris.upload(s->tri_recs)); SR_HIP(s->d_v9.upload(s->v9)); s->tris_dirty = false; s->cam_valid = false; }
     if (s->extra_dirty) { SR_HIP(s->d_extra.upload(s->extra_recs)); s->extra_dirty = false; }
     if (need_mode == SR_MODE_REF_TREE && s->ref_dirty) {
         SR_HIP(s->d_rnodes.upload(s->ref.nodes));
@@ -137,6 +139,7 @@ int sync_geometry(sr_scene* s, uint32_t need_mode) {
         SR_HIP(s->d_bslab.upload(slabs));
         s->bvh_num_nodes = s->bvh.nodes.size();
         s->bvh_dirty = false;
+        s->cam_valid = false;
     }
     return SR_OK;
 }
@@ -149,6 +152,8 @@ sr::DevScene dev_scene(const sr_scene* s) {
     d.rdepth = s->ref.tree_depth;
     d.bnodes = (const sr::BvhNode*)s->d_bnodes.p; d.btris = (const sr::Rec128*)s->d_btris.p; d.bdepth = s->bvh.depth;
     d.bslab = (const sr::TriSlab*)s->d_bslab.p;
+    d.bcam = s->cam_valid ? (const sr::CamCone*)s->d_bcam.p : nullptr;
+    d.v9 = (const double*)s->d_v9.p;
     d.bnode_bits = 1;
     while ((1ull << d.bnode_bits) < s->bvh_num_nodes + 1 && d.bnode_bits < 26) d.bnode_bits++;
     d.root = s->root;
@@ -300,6 +305,17 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         if (e1) SR_HIP(hipEventRecord(e1, stream));
         return SR_OK;
     }
+    // ---- camera-cone records of the packet primary walk: one pre-pass per (tree, ray origin) ----
+    if (f->trace_mode == SR_MODE_BVH && s->dbg[SR_DBG_PER_LANE_PRIMARY] <= 0 && !((f->flags & SR_F_FOCAL_BLUR) && f->sub_pixel_res > 1)) {
+        const size_t nt = s->tri_recs.size();
+        if (!s->cam_valid || s->cam_origin[0] != fc.start_world[0] || s->cam_origin[1] != fc.start_world[1] || s->cam_origin[2] != fc.start_world[2]) {
+            SR_HIP(s->d_bcam.reserve(nt * sizeof(sr::CamCone)));
+            s->cam_valid = false;
+            SR_HIP(sr::launch_cam_cones(dev_scene(s), (int)nt, fc.start_world, (sr::CamCone*)s->d_bcam.p, stream));
+            for (int i = 0; i < 3; ++i) s->cam_origin[i] = fc.start_world[i];
+            s->cam_valid = true;
+        }
+    }
     // ---- default: the primary / shadow / resolve pipeline, in row bands ----
     const long long n2 = (long long)fc.sub_pixel_res * fc.sub_pixel_res;
     const bool shadows = (fc.flags & SR_F_SHADOWS) != 0;
@@ -418,6 +434,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.per_lane_shadows = (f->flags & SR_F_PER_LANE_SHADOWS) != 0;
         P.exact_shadow_tests = s->dbg[SR_DBG_EXACT_SHADOW_TESTS] > 0;
         P.per_lane_shaft = s->dbg[SR_DBG_PER_LANE_SHAFT] > 0;
+        P.per_lane_primary = s->dbg[SR_DBG_PER_LANE_PRIMARY] > 0;
         P.stats = d_stats;
         P.stream = bs;
         P.user = s;
@@ -464,7 +481,7 @@ void sr_destroy(sr_scene* s) {
     if (!s) return;
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
-                        &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats};
+                        &s->d_v9, &s->d_bcam, &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats};
         for (DBuf* b : bufs) b->release();
         for (auto& sc : s->scratch) sc.release();
         if (s->fork) (void)hipEventDestroy(s->fork);
@@ -537,8 +554,8 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         if (rc) return rc;
         if ((rc = sync_geometry(s, SR_MODE_BRUTE))) return rc;            // d_tris
         const size_t n = s->argb.size();
-        DBuf d_v9, d_slab;
-        SR_HIP(d_v9.upload(s->v9));
+        DBuf d_slab;
+        DBuf& d_v9 = s->d_v9;                                             // uploaded by sync_geometry with the records
         {
             std::vector<sr::TriSlab> slabs(n);
             for (size_t i = 0; i < n; ++i) {
@@ -553,7 +570,6 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         int nn = 0, depth = 0;
         hipError_t e = sr::build_bvh_device((const double*)d_v9.p, (int)n, s->root, (const sr::Rec128*)s->d_tris.p, (const sr::TriSlab*)d_slab.p,
                                             (sr::BvhNode*)s->d_bnodes.p, (sr::Rec128*)s->d_btris.p, (sr::TriSlab*)s->d_bslab.p, &nn, &depth, nullptr);
-        d_v9.release();
         d_slab.release();
         if (e != hipSuccess) return hip_fail(e, "build_bvh_device");
         if (depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
@@ -563,6 +579,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         s->bvh_num_nodes = (size_t)nn;
         s->bvh_on_device = true;
         s->bvh_dirty = false;
+        s->cam_valid = false;
     } else if (modes & (1u << SR_MODE_BVH)) {
         sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(7, s->dbg[SR_DBG_BVH_LEAF]) : 4);
         if (s->bvh.depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");

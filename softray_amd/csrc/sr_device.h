@@ -22,6 +22,8 @@ struct DevScene {
     const BvhNode* bnodes;
     const Rec128*  btris;       // triangle records gathered in leaf order (aux = TriangleIndex)
     const TriSlab* bslab;       // fp32 shaft-prefilter records, same order as btris
+    const CamCone* bcam;        // fp32 camera-cone records of the current frame's ray origin, same order (nullptr: none)
+    const double*  v9;          // model vertices [ntris][3][3], TriangleIndex order
     int32_t        bdepth;
     int32_t        bnode_bits;  // bits needed for a BVH node index (stack words pack node | bound)
     RootBox        root;
@@ -79,6 +81,7 @@ struct PipelineLaunch {
     int32_t     row_first, row_limit; // compact rows [row_first, row_limit) of the frame are this launch's share
     int32_t     persistent_blocks;
     bool        per_lane_shadows; // force k_shadow (one lane per hit) instead of k_shadow_packet (cross-check)
+    bool        per_lane_primary; // k_primary with private walks instead of the packet walk + camera-cone filter (cross-check)
     bool        per_lane_shaft;   // k_shaft (private walks) also for the first round instead of k_shaft_pkt (cross-check)
     bool        exact_shadow_tests; // k_shadow_test (every pair in FP64) instead of k_shadow_cls (fp32 classification first)
     unsigned long long* stats;  // device [8] or nullptr
@@ -87,6 +90,8 @@ struct PipelineLaunch {
     void*       user;
 };
 hipError_t launch_pipeline(const PipelineLaunch& L);
+// per-frame pre-pass: camera-cone records of every BVH triangle for the ray origin `origin` (model space)
+hipError_t launch_cam_cones(const DevScene& sc, int ntris, const double origin[3], CamCone* out, hipStream_t stream);
 size_t pipeline_hit_record_bytes();
 size_t pipeline_static_cells();
 int pipeline_round_cap(int round);

@@ -52,13 +52,16 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 // k_primary
 // --------------------------------------------------------------------------------------------------
 // SUB = false: one ray per pixel (rayTraceSubPixelRes == 1), compiled without the sub-pixel / focal-blur state
-template <int MODE, bool EXTRA, bool STATS, bool SUB>
-__global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
+// PKT (own BVH, all rays of the frame share one origin): the wave walks the tree once (bvh_packet_nearest, sr_trace.h) and
+// consults the frame's camera-cone records before the FP64 triangle test
+template <int MODE, bool EXTRA, bool STATS, bool SUB, bool PKT>
+__global__ __launch_bounds__(256, (SUB || PKT) ? 5 : 6) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
                                                  int row_count, uint32_t* __restrict__ samples, HitRec* __restrict__ hits,
                                                  unsigned int* __restrict__ hit_count, uint32_t* __restrict__ bounce_levels,
-                                                 uint8_t* __restrict__ bounce_nlev, unsigned long long* stats, int pad_tiles) {
+                                                 uint8_t* __restrict__ bounce_nlev, unsigned long long* stats, int pad_tiles, int levels) {
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
+    int32_t* wnode = reinterpret_cast<int32_t*>(lds_pipe) + (size_t)__builtin_amdgcn_readfirstlane(wave) * levels;   // PKT: the wave's node stack
     // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup
     // L runs on XCD L % 8; the 1-D grid is mapped so that every XCD walks through its own 8x8-tile super-tiles
     // (128 x 128 pixels, neighbours share BVH nodes and triangle records in that XCD's L2), while at any time the eight
@@ -115,9 +118,14 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
         }
         Hit h;
         bool ok = false;
-        if (live) {
+        if (PKT) {
+            if (live) prim.rays++;
+            ok = root_intersect_pkt<EXTRA, true>(sc, sc.extra, wnode, live, ss, dw, h, prim);     // all 64 lanes take part
+        } else if (live) {
             prim.rays++;
             ok = root_intersect<MODE, false, EXTRA>(sc, sc.tris, sc.extra, st, ss, dw, h, prim);
+        }
+        if (live) {
             uint32_t color = fc.background;
             if (ok) color = (fc.flags & 1u) ? shade(fc, h.pos, h.nrm, h.color) : h.color;
             samples[sbase + si] = color;
@@ -1811,6 +1819,48 @@ __global__ __launch_bounds__(256) void k_static_apply(const uint8_t* __restrict_
 }
 
 // --------------------------------------------------------------------------------------------------
+// k_cam_cones: per-frame pre-pass of the packet primary walk -- the CamCone record (sr_types.h) of every BVH triangle for
+// the frame's ray origin O: FP64 cross products of the FP64 vertices, rounded once to fp32.  64 B written + 72 B (gathered)
+// + 8 B read per triangle: 0.15 GB at 1 M triangles; re-run only when the origin or the tree changed.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_cam_cones(const Rec128* __restrict__ btris, const TriSlab* __restrict__ bslab,
+                                                   const double* __restrict__ v9, int n, double ox, double oy, double oz,
+                                                   CamCone* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const Rec128* r = &btris[i];
+    const TriSlab sl = bslab[i];
+    CamCone c;
+    const bool degenerate = sl.n[0] == 0.0f && sl.n[1] == 0.0f && sl.n[2] == 0.0f;   // make_tri_slab: no usable planes
+    if (degenerate) {
+        for (int k = 0; k < 2; ++k) { c.w12x[k] = c.w12y[k] = c.w12z[k] = c.w3nx[k] = c.w3ny[k] = c.w3nz[k] = 0.0f; c.m12[k] = c.m3n[k] = 1e30f; }
+    } else {
+        const double* v = v9 + (size_t)r->aux * 9;
+        const D3 O = mk(ox, oy, oz);
+        const D3 a1 = mk(v[0], v[1], v[2]) - O, a2 = mk(v[3], v[4], v[5]) - O, a3 = mk(v[6], v[7], v[8]) - O;
+        auto ncross = [](D3 a, D3 b) { return mk(-(a.y * b.z - a.z * b.y), -(a.z * b.x - a.x * b.z), -(a.x * b.y - a.y * b.x)); };
+        const D3 w1 = ncross(a1, a2), w2 = ncross(a2, a3), w3 = ncross(a3, a1);
+        const float k8u = 8.0f * 5.9604645e-8f;
+        c.w12x[0] = (float)w1.x; c.w12y[0] = (float)w1.y; c.w12z[0] = (float)w1.z;
+        c.w12x[1] = (float)w2.x; c.w12y[1] = (float)w2.y; c.w12z[1] = (float)w2.z;
+        c.w3nx[0] = (float)w3.x; c.w3ny[0] = (float)w3.y; c.w3nz[0] = (float)w3.z;
+        c.w3nx[1] = (float)r->p[0]; c.w3ny[1] = (float)r->p[1]; c.w3nz[1] = (float)r->p[2];
+        c.m12[0] = k8u * (float)length(w1) * 1.0001f + 1e-37f;
+        c.m12[1] = k8u * (float)length(w2) * 1.0001f + 1e-37f;
+        c.m3n[0] = k8u * (float)length(w3) * 1.0001f + 1e-37f;
+        c.m3n[1] = k8u * 1.0001f;
+    }
+    out[i] = c;
+}
+
+hipError_t launch_cam_cones(const DevScene& sc, int ntris, const double origin[3], CamCone* out, hipStream_t stream) {
+    if (ntris <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_cam_cones, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, stream, sc.btris, sc.bslab, sc.v9, ntris,
+                       origin[0], origin[1], origin[2], out);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------------------------------
 // launchers
 // --------------------------------------------------------------------------------------------------
 static int pipe_stack_levels(const DevScene& sc, int mode) {
@@ -1819,20 +1869,31 @@ static int pipe_stack_levels(const DevScene& sc, int mode) {
     return 1;
 }
 
-template <int MODE, bool EXTRA, bool SUB>
-static hipError_t launch_primary_s(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples, int pad_tiles) {
+template <int MODE, bool EXTRA, bool SUB, bool PKT>
+static hipError_t launch_primary_p(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples, int pad_tiles) {
     // 1-D grid over the padded super-tile grid (see the tile order in k_primary)
     const int tiles_x = (L.fc.width + 15) / 16, tiles_y = (row_count + 15) / 16;
     const int spx = (((tiles_x + 7) / 8) + 7) / 8, sny = (tiles_y + 7) / 8;
     dim3 grid((unsigned)(spx * 8 * sny * 64));
-    size_t lds = (size_t)pipe_stack_levels(L.sc, MODE) * 256 * 4;
+    const int levels = pipe_stack_levels(L.sc, MODE);
+    size_t lds = PKT ? (size_t)levels * 4 * 4 : (size_t)levels * 256 * 4;
     if (L.stats)
-        hipLaunchKernelGGL((k_primary<MODE, EXTRA, true, SUB>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
-                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats, pad_tiles);
+        hipLaunchKernelGGL((k_primary<MODE, EXTRA, true, SUB, PKT>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
+                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats, pad_tiles, levels);
     else
-        hipLaunchKernelGGL((k_primary<MODE, EXTRA, false, SUB>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
-                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats, pad_tiles);
+        hipLaunchKernelGGL((k_primary<MODE, EXTRA, false, SUB, PKT>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
+                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats, pad_tiles, levels);
     return hipGetLastError();
+}
+
+template <int MODE, bool EXTRA, bool SUB>
+static hipError_t launch_primary_s(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples, int pad_tiles) {
+    if constexpr (MODE == MODE_BVH) {
+        // packet walk + camera-cone filter: the rays of the frame must share their origin (focal blur moves it per sub-sample)
+        const bool common_origin = !(SUB && (L.fc.flags & 4u));
+        if (L.sc.bcam && common_origin && !L.per_lane_primary) return launch_primary_p<MODE, EXTRA, SUB, true>(L, row_begin, row_count, samples, pad_tiles);
+    }
+    return launch_primary_p<MODE, EXTRA, SUB, false>(L, row_begin, row_count, samples, pad_tiles);
 }
 
 template <int MODE, bool EXTRA>

@@ -354,6 +354,134 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
 }
 
 // --------------------------------------------------------------------------------------------------
+// The same nearest-hit search for the 64 rays of one wavefront that share their ORIGIN (the camera rays of an 8x8-pixel
+// tile): the wave walks the BVH once -- shared stack of node indices in LDS (wave-uniform), node / triangle records
+// fetched with scalar loads, near child first by a vote -- and every lane tests its own ray against the broadcast boxes
+// and triangles.  Before the FP64 Triangle.IntersectRay a lane consults the triangle's camera-cone record (CamCone,
+// sr_types.h): if the ray is back-facing or outside one of the three cone planes by more than the fp32 error bound the
+// triangle cannot be hit (every condition of Triangle.cs:83-104 that fails does so by ~1e-7 relative, the FP64 noise is
+// 1e-16), so the exact test is skipped; everything that can become a hit runs the reference arithmetic unchanged.
+// Result per lane == bvh_intersect<false> (a different but equally conservative visiting order; the nearest hit with
+// the lowest-index tie-break does not depend on the order).  All 64 lanes must call it (live = false: no ray).
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool cone_rejects(const CamCone& cm, f2 dxx, f2 dyy, f2 dzz, float dl) {
+    // (c1, c2) and (c3, n.d): two packed FMA chains
+    const f2 c12 = pk_fma((f2){cm.w12x[0], cm.w12x[1]}, dxx, pk_fma((f2){cm.w12y[0], cm.w12y[1]}, dyy, (f2){cm.w12z[0], cm.w12z[1]} * dzz));
+    const f2 c3n = pk_fma((f2){cm.w3nx[0], cm.w3nx[1]}, dxx, pk_fma((f2){cm.w3ny[0], cm.w3ny[1]}, dyy, (f2){cm.w3nz[0], cm.w3nz[1]} * dzz));
+    const f2 m12 = (f2){cm.m12[0], cm.m12[1]} * splat(dl), m3n = (f2){cm.m3n[0], cm.m3n[1]} * splat(dl);
+    // outside a cone plane: c_k < -m_k |d|;  back-facing: n.d > mn |d|  (dirDist >= 0, Plane.cs:60-61)
+    return fminf(fminf(c12.x + m12.x, c12.y + m12.y), c3n.x + m3n.x) < 0.0f || c3n.y > m3n.y;
+}
+
+template <bool FILTER>
+__device__ bool bvh_packet_nearest(const DevScene& sc, int32_t* wnode, bool live, D3 s, D3 d, Hit& out, Ctr& c) {
+    D3 end = s + d * 10000.0;
+    D3 original = s;
+    bool act = live;
+    if (act) act = clip_segment<false>(sc.root, s, end);
+    const double offset = act ? length(original - s) / length(d) : 0.0;
+    const float ox = (float)(s.x - sc.root.centre[0]), oy = (float)(s.y - sc.root.centre[1]), oz = (float)(s.z - sc.root.centre[2]);
+    const float dfx = (float)d.x, dfy = (float)d.y, dfz = (float)d.z;
+    const float ix = slab_inv(dfx), iy = slab_inv(dfy), iz = slab_inv(dfz);
+    const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
+    const f2 B0 = {-ox * ix, -oy * iy}, B1 = {-oz * iz, -ox * ix}, B2 = {-oy * iy, -oz * iz};
+    const f2 dxx = splat(dfx), dyy = splat(dfy), dzz = splat(dfz);
+    const float dl = sqrtf(dfx * dfx + dfy * dfy + dfz * dfz) * 1.000001f;
+    const float kInfl = 1.0f + 9.5367431640625e-7f;          // 1 + 2^-20
+    float tlim = FLT_MAX;
+    double best = DBL_MAX;
+    int32_t bestIdx = 0x7fffffff, bestK = -1;
+    int sp = 0;                      // wave-uniform
+    int32_t ni = 0;                  // wave-uniform
+    if (__ballot(act) != 0ull) {
+        for (;;) {
+            const BvhNode n = sc.bnodes[ni];                           // wave-uniform address: scalar loads
+            if (act) c.nodes++;
+            float t0, x0, t1, x1;
+            node_slabs(n, I01, I20, I12, B0, B1, B2, t0, x0, t1, x1);
+            const bool h0 = act && n.n0 >= 0 && t0 <= x0 && x0 >= 0.0f && t0 <= tlim;
+            const bool h1 = act && n.n1 >= 0 && t1 <= x1 && x1 >= 0.0f && t1 <= tlim;
+            const bool first0 = __popcll(__ballot(h0 && h1 && t0 <= t1)) >= __popcll(__ballot(h0 && h1 && t1 < t0));
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const bool c0 = (t == 0) == first0;
+                const int cn = c0 ? n.n0 : n.n1, cc = c0 ? n.c0 : n.c1;
+                const bool hc = (c0 ? h0 : h1) && (c0 ? t0 : t1) <= tlim;       // tlim may have shrunk in the other leaf
+                if (cn > 0 && __ballot(hc) != 0ull) {
+                    if (hc) c.leaves++;
+                    for (int k = cc; k < cc + cn; ++k) {
+                        bool cand = hc;
+                        if (FILTER) {
+                            const CamCone cm = sc.bcam[k];                       // scalar load
+                            cand = hc && !cone_rejects(cm, dxx, dyy, dzz, dl);
+                        }
+                        if (hc) c.geom++;
+                        if (__ballot(cand) != 0ull) {
+                            const Rec128* r = &sc.btris[k];                       // wave-uniform address
+                            if (cand) {
+                                double tt; D3 pos;
+                                if (tri_hit(r->p, s, d, tt, pos) && inside(sc.root.lo, sc.root.hi, pos)) {
+                                    const int32_t idx = r->aux;
+                                    if (tt < best || (tt == best && idx < bestIdx)) {
+                                        best = tt; bestIdx = idx; bestK = k;
+                                        tlim = (float)best * kInfl + 1e-30f;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            const bool w0 = h0 && n.n0 == 0 && t0 <= tlim, w1 = h1 && n.n1 == 0 && t1 <= tlim;
+            const bool any0 = __ballot(w0) != 0ull, any1 = __ballot(w1) != 0ull;
+            if (any0 && any1) {
+                wnode[sp++] = first0 ? n.c1 : n.c0;                    // (all lanes write the same word)
+                ni = first0 ? n.c0 : n.c1;
+            } else if (any0) ni = n.c0;
+            else if (any1) ni = n.c1;
+            else {
+                if (sp == 0) break;
+                ni = __builtin_amdgcn_readfirstlane(wnode[--sp]);
+            }
+        }
+    }
+    if (bestK < 0) return false;
+    const Rec128* r = &sc.btris[bestK];
+    out.t = best + offset;
+    out.pos = s + d * best;          // the expression plane_hit evaluated for the winning triangle (pos = start + dir * rayFrac)
+    out.nrm = mk(r->p[0], r->p[1], r->p[2]);
+    out.color = r->color;
+    out.tri = r->aux;
+    return true;
+}
+
+// root of the chain for a wavefront of rays with a common origin: extra geometry per lane, then the packet walk
+template <bool EXTRA, bool FILTER>
+__device__ bool root_intersect_pkt(const DevScene& sc, const Rec128* extra, int32_t* wnode, bool live, D3 s, D3 d, Hit& out, Ctr& c) {
+    bool any = false;
+    double best = DBL_MAX;
+    if (EXTRA && live) {
+        for (int i = 0; i < sc.nextra; ++i) {
+            const Rec128* r = &extra[i];
+            double t; D3 pos, nrm;
+            bool ok;
+            int kind = r->aux;
+            if (kind == 0) ok = sphere_hit(r->p, s, d, t, pos, nrm);
+            else if (kind == 1) { ok = plane_hit(r->p, s, d, t, pos); nrm = mk(r->p[0], r->p[1], r->p[2]); }
+            else { ok = tri_hit(r->p, s, d, t, pos); nrm = mk(r->p[0], r->p[1], r->p[2]); }
+            c.geom++;
+            if (ok && t < best) {
+                best = t; any = true;
+                out.t = t; out.pos = pos; out.nrm = nrm; out.color = r->color; out.tri = -1;
+            }
+        }
+    }
+    Hit mh;
+    if (bvh_packet_nearest<FILTER>(sc, wnode, live, s, d, mh, c) && mh.t < best) { out = mh; any = true; }
+    return any;
+}
+
+// --------------------------------------------------------------------------------------------------
 // Blocker cache for any-hit (shadow) rays: "does THIS triangle record occlude the ray" with exactly the
 // predicate of the full traversal (same clip, same rayFrac offset, same root-box containment).  Any
 // triangle that satisfies it proves rayFrac <= 1.0 for the nearest hit, which is all ShadowMethod.cs:170

@@ -66,6 +66,19 @@ struct alignas(16) TriSlab {
 };
 static_assert(sizeof(TriSlab) == 64, "TriSlab must be 64 bytes");
 
+// fp32 description of one triangle as seen from ONE ray origin O (the camera of a frame), 64 B = one line, BVH-leaf order,
+// laid out in pairs for packed FMAs: with a_i = v_i - O, the cone planes w1 = -(a1 x a2), w2 = -(a2 x a3), w3 = -(a3 x a1)
+// (computed in FP64, rounded once) and the reference's unit plane normal n.  A ray O + t d can only hit the triangle
+// (Triangle.IntersectRay) if w_k . d >= 0 for k = 1..3 (front side) and n . d < 0; m_k = 8 * 2^-24 * |w_k| bounds the fp32
+// evaluation error of w_k . d per unit |d|.  Degenerate triangles: all zeros with huge margins (never filtered).
+struct alignas(16) CamCone {
+    float w12x[2], w12y[2], w12z[2];   // (w1.x, w2.x) (w1.y, w2.y) (w1.z, w2.z)
+    float w3nx[2], w3ny[2], w3nz[2];   // (w3.x, n.x) (w3.y, n.y) (w3.z, n.z)
+    float m12[2];                      // (m1, m2)
+    float m3n[2];                      // (m3, mn)
+};
+static_assert(sizeof(CamCone) == 64, "CamCone must be 64 bytes");
+
 // Root box as the clip needs it (AxisAlignedBox.cs:16-28,143-149)
 struct RootBox {
     double min[3], max[3];       // model.Min / model.Max

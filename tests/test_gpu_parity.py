@@ -30,7 +30,18 @@ def render_both(g, frame, mode=None):
     a, sa_ = g.render(as_sr(frame, mode))
     b, sb_ = g.render(as_sr(frame, mode, single_kernel=True))
     assert np.array_equal(a, b), "pipeline and single-kernel renderer differ"
-    assert np.array_equal(sa_, sb_)
+    used = frame.trace_mode if mode is None else mode
+    if used == sa.MODE_BVH:
+        # on the own BVH the node / triangle-test counters are the schedule's (the pipeline walks the tree once per 8x8-pixel
+        # tile, the one-kernel renderer once per ray); rays fired is the reference's notion and must agree.  With private
+        # walks in both (sr_debug_set) the counters agree entirely
+        assert sa_[0] == sb_[0]
+        g.debug_set(sa._lib.DBG_PER_LANE_PRIMARY, 1)
+        a2, sa2 = g.render(as_sr(frame, mode))
+        g.debug_set(sa._lib.DBG_PER_LANE_PRIMARY, -1)
+        assert np.array_equal(a2, a) and np.array_equal(sa2, sb_)
+    else:
+        assert np.array_equal(sa_, sb_)
     if frame.flags & sa.F_SHADOWS:
         c, _ = g.render(as_sr(frame, mode, per_lane=True))
         assert np.array_equal(a, c), "k_shadow_packet and k_shadow differ"
@@ -416,6 +427,48 @@ def test_packet_shaft_walk_against_private_walks():
                 got, _ = g.render(as_sr(f, sa.MODE_BVH))
                 assert np.array_equal(got, want), (kw, caps, per_lane)
     g.debug_set(sa._lib.DBG_PER_LANE_SHAFT, -1)
+
+
+def test_packet_primary_walk_against_private_walks():
+    """k_primary's packet walk (one traversal per 8x8-pixel tile, camera-cone records filter the FP64 triangle tests) against
+    the private per-lane walks and the oracle: odd frame sizes, AA sub-samples (same origin), focal blur (origins differ: the
+    packet walk must step aside), extra geometry, a camera inside the root box, a moved camera (cone records re-made), the
+    mirror-bounce pipeline, and ray statistics that stay deterministic."""
+    v9, argb, bmin, bmax = unit_cube_scene(30000)
+    g = sa.GpuScene(0); o = orc.Scene()
+    for s_ in (g, o):
+        s_.set_triangles(v9, argb, bmin, bmax)
+    g.build((sa.MODE_BVH,)); assert o.build_tree() == 0
+    cases = [dict(), dict(sub_pixel_res=3), dict(sub_pixel_res=2, focal_blur=True), dict(depth=0.2), dict(yaw_deg=300.0, pitch_deg=40.0, roll_deg=25.0),
+             dict(shadows=True), dict(start_row=9, end_row=40)]
+    for kw in cases:
+        kw = dict(kw)
+        depth = kw.pop("depth", 1.5)
+        f = make_frame(107, 85, depth=depth, **kw)
+        want, _ = o.render(f, threads=NCPU)
+        stats = []
+        for per_lane in (0, 1):
+            g.debug_set(sa._lib.DBG_PER_LANE_PRIMARY, per_lane)
+            got, st = g.render(as_sr(f, sa.MODE_BVH))
+            assert np.array_equal(got, want), (kw, per_lane)
+            again, st2 = g.render(as_sr(f, sa.MODE_BVH))
+            assert np.array_equal(st, st2)
+            stats.append(st)
+        assert stats[0][0] == stats[1][0]                  # rays fired
+    g.debug_set(sa._lib.DBG_PER_LANE_PRIMARY, -1)
+    prims = c1_spheres(7)
+    prims.append((1, 0xff808080, [0, -0.45, 0, 0, 1, 0]))
+    g.set_extra(prims); o.set_extra(prims)
+    f = make_frame(96, 72, depth=1.8)
+    assert np.array_equal(g.render(as_sr(f, sa.MODE_BVH))[0], o.render(f, threads=NCPU)[0])
+    f.max_bounces, f.reflectivity = 3, 0.5
+    assert np.array_equal(g.render(as_sr(f, sa.MODE_BVH))[0], o.render(f, threads=NCPU)[0])
+    # the golden model through the packet walk
+    g2 = sa.GpuScene(0)
+    g2.load_3ds(open(os.path.join(GOLDEN, "obj.3ds"), "rb").read())
+    g2.build((sa.MODE_BVH,))
+    got, _ = g2.render(as_sr(make_frame(100), sa.MODE_BVH))
+    assert int(np.count_nonzero((got.reshape(100, 100) & 0xFFFFFF) != golden_rgb("shading", 100))) == 0
 
 
 def test_full_size_properties():
