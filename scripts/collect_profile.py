@@ -15,7 +15,7 @@ def ours(row):
 
 
 def family(name):
-    for k in ("k_primary", "k_shaft", "k_shadow_test", "k_shadow_wave", "k_shadow_rays", "k_fb_expand", "k_fb_resolve", "k_post_process", "k_anti_alias"):
+    for k in ("k_primary", "k_cam_cones", "k_shaft_pkt", "k_shaft", "k_shadow_cls", "k_shadow_test", "k_shadow_wave", "k_shadow_rays", "k_fb_expand", "k_fb_resolve", "k_post_process", "k_anti_alias"):
         if k in name:
             return k
     return None
@@ -34,11 +34,11 @@ traffic = collections.defaultdict(float)
 for pmc, mul in (("pmc_fetch", 2.0), ("pmc_write", 1.0)):
     for r in csv.DictReader(open(os.path.join(src, pmc, "pmc_counter_collection.csv"))):
         fam = family(r["Kernel_Name"])
-        if fam in ("k_primary", "k_shaft", "k_shadow_test", "k_shadow_wave", "k_shadow_rays", "k_fb_expand", "k_fb_resolve") and "true>" not in r["Kernel_Name"].split("(")[0]:
+        if fam in ("k_primary", "k_cam_cones", "k_shaft_pkt", "k_shaft", "k_shadow_cls", "k_shadow_test", "k_shadow_wave", "k_shadow_rays", "k_fb_expand", "k_fb_resolve") and "true>" not in r["Kernel_Name"].split("(")[0]:
             traffic[fam] += mul * float(r["Counter_Value"]) * 1024.0
 # k_primary also runs 3 primary-only frames at the end of bench.py: 9 launches in total
-per_frame = {"k_primary": traffic["k_primary"] / 9.0, "k_shaft": traffic["k_shaft"] / frames,
-             "k_shadow": (traffic["k_shadow_test"] + traffic["k_shadow_wave"] + traffic["k_shadow_rays"] + traffic["k_fb_expand"] + traffic["k_fb_resolve"]) / frames}
+per_frame = {"k_primary": traffic["k_primary"] / 9.0, "k_shaft": (traffic["k_shaft"] + traffic["k_shaft_pkt"]) / frames,
+             "k_shadow": (traffic["k_shadow_cls"] + traffic["k_shadow_test"] + traffic["k_shadow_wave"] + traffic["k_shadow_rays"] + traffic["k_fb_expand"] + traffic["k_fb_resolve"]) / frames}
 hb = {"bvh_1000000_4096_100": per_frame,
       "_how": "HBM bytes per FRAME of each kernel family = sum over its launches of (2*FETCH_SIZE + WRITE_SIZE)*1024, rocprofv3 --pmc "
               "FETCH_SIZE / --pmc WRITE_SIZE in separate passes (%s), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for "

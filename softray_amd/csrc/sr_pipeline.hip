@@ -1073,6 +1073,17 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
     float4* wc = reinterpret_cast<float4*>(lds_pipe) + (size_t)wave * (kClsCand * 5 + kClsCand / 4);
     int32_t* wrecidx = reinterpret_cast<int32_t*>(wc + kClsCand * 5);    // record position of every staged candidate
     const int S = fc.shadow_samples;
+    // ShadowMethod.IntersectRay's byte for every possible rayEscapeCount (:113-119 / the static cache's :80), made once per
+    // workgroup with the reference's FP64 expressions instead of one FP64 division per hit point
+    uint32_t* light_byte = reinterpret_cast<uint32_t*>(reinterpret_cast<float4*>(lds_pipe) + 4 * (kClsCand * 5 + kClsCand / 4));
+    for (int e = tid; e <= S; e += 256) {
+        const double frac = (double)e / (double)S;
+        uint32_t v;
+        if (fc.flags & 32u) { v = (uint32_t)(int)(frac * 254 + 1) & 0xffu; v = v ? v : 1u; }
+        else v = to_byte(frac * 255);
+        light_byte[e] = v;
+    }
+    __syncthreads();
     const unsigned int total = min(*hit_count, count_cap);
     const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
     const ClsFrame cf = cls_frame(sc, fc);
@@ -1135,13 +1146,11 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
         const D3 DLd = lpos - E;
         const float efx = (float)(E.x - sc.root.centre[0]), efy = (float)(E.y - sc.root.centre[1]), efz = (float)(E.z - sc.root.centre[2]);
         const float dlx = (float)DLd.x, dly = (float)DLd.y, dlz = (float)DLd.z;
-        const float dmax = sqrtf(dlx * dlx + dly * dly + dlz * dlz) * 1.0001f + cf.R;
+        const float dmax = __builtin_amdgcn_sqrtf(dlx * dlx + dly * dly + dlz * dlz) * 1.0001f + cf.R;   // an upper bound is all it has to be
         const float a1 = 20.0f * kU24 * dmax, glo = 16.0f * a1;
         const float pm = 5e-7f * (cf.s0 + dmax);                        // position error bound of E' + u D_i in fp32 (>= 4u (|E'| + u |D|))
-        const bool ein = fabsf(efx) < cf.hbx - pm && fabsf(efy) < cf.hby - pm && fabsf(efz) < cf.hbz - pm;
         // ---- per (hit point, sample): state + umax ----
         bool alive[kPacketSlots], escaped[kPacketSlots];
-        float umax[kPacketSlots];
 #pragma unroll
         for (int q = 0; q < kPacketSlots; ++q) {
             alive[q] = false;
@@ -1157,20 +1166,26 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                 if (blocked) escaped[q] = false;
                 else alive[q] = work;
             }
-            const float ox = q ? OX.y : OX.x, oy = q ? OY.y : OY.x, oz = q ? OZ.y : OZ.x;
-            const float dx = dlx + ox, dy = dly + oy, dz = dlz + oz;
-            const float rx = slab_inv(dx), ry = slab_inv(dy), rz = slab_inv(dz);
-            float ue = (__builtin_copysignf(cf.hbx, dx) - efx) * rx, re = rx;
-            const float ty = (__builtin_copysignf(cf.hby, dy) - efy) * ry, tz = (__builtin_copysignf(cf.hbz, dz) - efz) * rz;
-            if (ty < ue) { ue = ty; re = ry; }
-            if (tz < ue) { ue = tz; re = rz; }
-            if (1.0f < ue) { ue = 1.0f; re = 1.0f; }
-            const float ut = ue - (3.0f * pm * fabsf(re) + 1e-5f * ue + 1e-7f);
-            const float px = __builtin_fmaf(ut, dx, efx), py = __builtin_fmaf(ut, dy, efy), pz = __builtin_fmaf(ut, dz, efz);
-            const bool ok = ein && ut > 0.0f && fabsf(px) < cf.hbx - pm && fabsf(py) < cf.hby - pm && fabsf(pz) < cf.hbz - pm;
-            umax[q] = ok ? ut : -1.0f;
         }
-        const f2 UM = {umax[0], umax[1]};
+        // umax_i: the exit parameter of the ray from a box shrunk by 4 pm (any approximation will do: fast reciprocals), then
+        // the point E' + umax_i D_i is VERIFIED to lie inside the root box by more than pm, and so is E'.  Packed over the
+        // lane's two samples.
+        f2 UM;
+        {
+            const float sx = cf.hbx - 4.0f * pm, sy = cf.hby - 4.0f * pm, sz = cf.hbz - 4.0f * pm;
+            const bool ein = fabsf(efx) < sx && fabsf(efy) < sy && fabsf(efz) < sz;
+            const f2 dxv = OX + splat(dlx), dyv = OY + splat(dly), dzv = OZ + splat(dlz);
+            const f2 rx = {__builtin_amdgcn_rcpf(dxv.x), __builtin_amdgcn_rcpf(dxv.y)}, ry = {__builtin_amdgcn_rcpf(dyv.x), __builtin_amdgcn_rcpf(dyv.y)},
+                     rz = {__builtin_amdgcn_rcpf(dzv.x), __builtin_amdgcn_rcpf(dzv.y)};
+            const f2 tx = ((f2){__builtin_copysignf(sx, dxv.x), __builtin_copysignf(sx, dxv.y)} - splat(efx)) * rx;
+            const f2 ty = ((f2){__builtin_copysignf(sy, dyv.x), __builtin_copysignf(sy, dyv.y)} - splat(efy)) * ry;
+            const f2 tz = ((f2){__builtin_copysignf(sz, dzv.x), __builtin_copysignf(sz, dzv.y)} - splat(efz)) * rz;
+            const f2 ut = {fminf(fminf(fminf(tx.x, ty.x), tz.x), 0.999999f), fminf(fminf(fminf(tx.y, ty.y), tz.y), 0.999999f)};
+            const f2 px = pk_fma(ut, dxv, splat(efx)), py = pk_fma(ut, dyv, splat(efy)), pz = pk_fma(ut, dzv, splat(efz));
+            const bool ok0 = ein && ut.x > 0.0f && fabsf(px.x) < cf.hbx - pm && fabsf(py.x) < cf.hby - pm && fabsf(pz.x) < cf.hbz - pm;
+            const bool ok1 = ein && ut.y > 0.0f && fabsf(px.y) < cf.hbx - pm && fabsf(py.y) < cf.hby - pm && fabsf(pz.y) < cf.hbz - pm;
+            UM = (f2){ok0 ? ut.x : -1.0f, ok1 ? ut.y : -1.0f};
+        }
         const float hbm = cf.a0 + a1;
         bool have = __any(alive[0] || alive[1]);
         for (int base = 0; base < ntri && have; base += kClsCand) {
@@ -1287,9 +1302,9 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
             }
         } else {
             const int esc = (int)__popcll(__ballot(escaped[0])) + (int)__popcll(__ballot(escaped[1]));
-            if (lane == 0) {
-                double frac = (double)esc / (double)S;                     // ShadowMethod.IntersectRay :113-119
-                finish_hit(sc, fc, samples, rec.sample, rec.pad[0], shaded, frac);
+            if (lane == 0) {                                               // finish_hit with the tabulated byte
+                if (fc.flags & 32u) sc.shadow_cache[rec.pad[0]] = (uint8_t)light_byte[esc];
+                else samples[rec.sample] = modulate(shaded, light_byte[esc]);
             }
         }
     }
@@ -1989,7 +2004,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
             const unsigned int* t_list = first ? L.round_list[0] : ilist;
             if (!L.exact_shadow_tests) {
                 // default: fp32 classification, FP64 only for the pairs it cannot decide
-                const size_t lds_c = 4 * ((size_t)kClsCand * 5 + kClsCand / 4) * sizeof(float4);
+                const size_t lds_c = 4 * ((size_t)kClsCand * 5 + kClsCand / 4) * sizeof(float4) + (64 * kPacketSlots + 1) * sizeof(uint32_t);
                 if (L.stats) hipLaunchKernelGGL((k_shadow_cls<EXTRA, true>), dim3(blocks), dim3(256), lds_c, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
                 else hipLaunchKernelGGL((k_shadow_cls<EXTRA, false>), dim3(blocks), dim3(256), lds_c, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
             } else if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
