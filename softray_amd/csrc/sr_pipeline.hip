@@ -366,88 +366,85 @@ constexpr unsigned kTruncated = 0x80000000u;
 constexpr unsigned kUmbraItem = 0x40000000u;   // cand_count of a later round: k_shaft found an umbra triangle
 
 // The shaft is parametrised from the surface end: C(u) = E' + u (L - E'), u in [0, 1] (u = 1 - t), so that all fp32
-// quantities are small near the surface point (robust for distant lights); sample rays deviate from C(u) by at most
-// R u.  Can any point of the centre segment, u in [ua, ub], lie within rho of the triangle?  Necessary condition
-// (conservative): the segment meets the slab |n.x - d| <= rho and the three edge half-spaces m_k.x - c_k >= -rho.
-// Each constraint is linear in u, so it clips the interval.
-// k_shaft is fp32 VALU-throughput bound (SQ_ACTIVE_INST_VALU ~ 90 % of the SIMD cycles), so its inner parts are
-// written for instruction count: packed fp32 FMAs (v_pk_fma_f32: two lanes of a register pair per issue slot),
-// select-free interval clipping, v_rcp_f32 instead of IEEE divisions.  All of it is conservative filtering (the exact
-// FP64 tests run in k_shadow_test), so fused / reordered roundings are covered by the pads.
+// quantities are small near the surface point (robust for distant lights).  Every sample ray leaves E' in a direction
+// D = DL + off, DL = L - E', |off| <= R.  Which triangles can such a ray hit?  With the triangle's TriSlab planes (unit
+// normal n, unit in-plane edge normals m_k pointing inward; n, m_k orthonormal) and G0 = n.E' - d, N1 = n.DL,
+// K0_k = m_k.E' - c_k, K1_k = m_k.DL: the ray meets the plane at u_c = -G0 / (N1 + n.off) and lies inside edge k there
+// iff w_k.D >= 0 with w_k = K0_k n - G0 m_k, the normal of the plane through E' and edge k (see k_shadow_cls).  Since
+//     w_k.DL = K0_k N1 - G0 K1_k =: A_k        and        |w_k| = sqrt(K0_k^2 + G0^2) =: L_k        (n is orthogonal to m_k)
+// the extremes of w_k.D over the ball of offsets are A_k +- R L_k -- no vector arithmetic at all:
+//   candidate  <=  N1 + R >= 0 (front-facing for some sample), G0 <= 0 (plane between light and surface point), G0 + N1 + R >= 0
+//                  (some sample starts in front of the plane) and A_k + R L_k >= 0 for k = 1..3 (some direction inside edge k);
+//   UMBRA      <=  N1 - R > 0, G0 < 0 and A_k - R L_k > 0 for k = 1..3 (EVERY direction of the ball inside every edge), and the
+//                  crossing region inside the root box: Triangle.IntersectRay accepts the crossing of every sample with
+//                  rayFrac <= 1.0 (ShadowMethod.cs:170), so rayEscapeCount = 0 whatever the samples are.
+// Each necessary condition is tested on its own (not for one common offset): conservative.  fp32 error bounds as in
+// k_shadow_cls: |G0|, |K0_k| errors < a0 = 12u s0, |N1|, |K1_k| errors < a1 = 20u dmax, |A_k - true| < eps_k = dmax u (15 s0 + 16 (|K0_k| + |G0|));
+// the candidate tests are relaxed and the umbra tests tightened by these.  The kernels are fp32 VALU-throughput bound, so this
+// is written for instruction count: packed FMAs for the eight plane functions, v_sqrt_f32 for L_k (its error is far below eps).
 struct ShaftRay {
     f2    edx, edy, edz;        // per axis (E' , L - E'): value and slope of the centre ray C(u) = E' + u (L - E')
-    float R, pad, ext, hbx, hby, hbz;
-    float backface;             // R * 1.001 + 1e-6 * |L - E'|_1: see shaft_touches
+    float R, Rm, hbx, hby, hbz;
+    float backface;             // R * 1.001 + 1e-6 * |L - E'|_1
+    float a0, a01;              // a0; a0 + a1 + (Rm - R)
+    float c0, c1;               // eps_k = c0 + c1 (|K0_k| + |G0|)
+    float umargin;              // 3e-5 * extent: slack of the umbra's root-box test
 };
 
-// reciprocal slope of a linear function f0 + u f1; a (nearly) zero slope acts as a huge positive one: the function is
-// constant over u in [0, 1] to far below the pads, and the clip below then keeps everything when f0 satisfies the bound
-// and nothing otherwise.  The result is always finite, so the clips never see inf * 0.
-__device__ __forceinline__ float slope_inv(float f1) { return fabsf(f1) < 1e-30f ? 1e30f : __builtin_amdgcn_rcpf(f1); }
-// |f0 + u f1| <= rho
-__device__ __forceinline__ void clip_abs(float f0, float inv, float rho, float& ua, float& ub) {
-    const float v1 = (-rho - f0) * inv, v2 = (rho - f0) * inv;
-    ua = fmaxf(ua, fminf(v1, v2));
-    ub = fminf(ub, fmaxf(v1, v2));
+__device__ __forceinline__ ShaftRay make_shaft_ray(const DevScene& sc, const FrameConst& fc, D3 E, D3 lpos) {
+    ShaftRay sr;
+    const float R = (float)fc.light_radius * 1.00001f + 1e-30f;
+    const float bx = (float)(sc.root.max[0] - sc.root.min[0]), by = (float)(sc.root.max[1] - sc.root.min[1]), bz = (float)(sc.root.max[2] - sc.root.min[2]);
+    const float ext = fmaxf(fmaxf(bx, by), bz);
+    const float ex = (float)(E.x - sc.root.centre[0]), ey = (float)(E.y - sc.root.centre[1]), ez = (float)(E.z - sc.root.centre[2]);
+    const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
+    sr.edx = (f2){ex, dx}; sr.edy = (f2){ey, dy}; sr.edz = (f2){ez, dz};
+    sr.R = R; sr.Rm = R * 1.001f;
+    sr.backface = R * 1.001f + 1e-6f * (fabsf(dx) + fabsf(dy) + fabsf(dz)) + 1e-30f;
+    sr.hbx = 0.5f * bx; sr.hby = 0.5f * by; sr.hbz = 0.5f * bz;
+    // |E'| may exceed the half diagonal by the probe offset; s0 as in cls_frame, evaluated with the actual |E'|
+    const float s0 = (__builtin_amdgcn_sqrtf(bx * bx + by * by + bz * bz) * 0.5f + fabsf(ex) + fabsf(ey) + fabsf(ez)) * 1.002f + 0.004f;
+    const float dmax = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * 1.0001f + R;
+    const float u = 5.9604645e-8f;
+    sr.a0 = 12.0f * u * s0;
+    sr.a01 = sr.a0 + 20.0f * u * dmax + 0.002f * R;
+    sr.c0 = 15.0f * u * s0 * dmax + 1e-9f * dmax;
+    sr.c1 = 16.0f * u * dmax;
+    sr.umargin = 3e-5f * ext;
+    return sr;
 }
-// f0 + u f1 >= -rho;  big = copysign(1e30, inv): the open end of the half line
-__device__ __forceinline__ void clip_ge(float f0, float inv, float big, float rho, float& ua, float& ub) {
-    const float v = (-rho - f0) * inv;
-    ua = fmaxf(ua, fminf(v, big));
-    ub = fminf(ub, fmaxf(v, big));
-}
-// returns 0: no sample ray can touch the triangle; 1: candidate; 2: UMBRA -- every possible sample ray crosses this
-// triangle well inside it, in front of the surface point: the hit point is fully shadowed whatever the samples are.
-//
-// Umbra argument (all margins are orders of magnitude above the fp32 evaluation error): a sample ray deviates from the
-// centre ray by at most R u at parameter u.  With g(u) = n.C(u) - d = n0 + u n1 and n1 > R (front-facing for every
-// sample direction), a sample crosses the plane at some u_i with |g(u_i)| <= R u_i, i.e. u_i in [ulo, uhi] =
-// [-n0/(n1+R), -n0/(n1-R)].  Its crossing point is within R uhi of C(u_i), so edge function k there is at least
-// min over [ulo, uhi] of (k0 + u k1) - R uhi.  If that exceeds the margin for the three edges, the crossing lies
-// strictly inside the triangle (hence inside the root box), at 0 < t < 1: Triangle.IntersectRay accepts it and
-// rayFrac <= 1.0 for every sample (ShadowMethod.cs:170), so rayEscapeCount = 0.
-__device__ __forceinline__ int shaft_touches(const TriSlab s, const ShaftRay& sr, float ua, float ub) {
+
+// returns 0: no sample ray can hit the triangle; 1: candidate; 2: UMBRA
+__device__ __forceinline__ int shaft_touches(const TriSlab s, const ShaftRay& sr) {
     // (f0, f1) of the plane and the three edge planes along the centre ray, two lanes per packed FMA
     f2 cn = {-s.d, 0.0f}, c1 = {-s.c1, 0.0f}, c2 = {-s.c2, 0.0f}, c3 = {-s.c3, 0.0f};
     const f2 N = pk_fma(splat(s.n[0]), sr.edx, pk_fma(splat(s.n[1]), sr.edy, pk_fma(splat(s.n[2]), sr.edz, cn)));
     const f2 P = pk_fma(splat(s.m1[0]), sr.edx, pk_fma(splat(s.m1[1]), sr.edy, pk_fma(splat(s.m1[2]), sr.edz, c1)));
     const f2 Q = pk_fma(splat(s.m2[0]), sr.edx, pk_fma(splat(s.m2[1]), sr.edy, pk_fma(splat(s.m2[2]), sr.edz, c2)));
     const f2 T = pk_fma(splat(s.m3[0]), sr.edx, pk_fma(splat(s.m3[1]), sr.edy, pk_fma(splat(s.m3[2]), sr.edz, c3)));
-    // Triangle.IntersectRay is one-sided (dirDist >= 0 -> no hit, Triangle.cs / Plane.cs:60-61): dirDist of sample i is
-    // -n.(D + off_i) with |n.off_i| <= R, so a triangle with n.D + R < 0 faces away from EVERY sample ray and can never block
-    // one.  backface = R + fp32 slack (plane rounding + dot product, < 1e-6 |D|_1), computed per hit point.
-    if (N.y < -sr.backface) return 0;
-    const float in = slope_inv(N.y), ip = slope_inv(P.y), iq = slope_inv(Q.y), it3 = slope_inv(T.y);
-    const float bp = __builtin_copysignf(1e30f, ip), bq = __builtin_copysignf(1e30f, iq), bt = __builtin_copysignf(1e30f, it3);
-    // the shaft radius at the far end of the current interval bounds the deviation; clipping shrinks the interval,
-    // which shrinks the radius: one refinement
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const float rho = __builtin_fmaf(sr.R, fminf(1.0f, fmaxf(0.0f, ub + 1e-5f)), sr.pad);
-        clip_abs(N.x, in, rho, ua, ub);
-        clip_ge(P.x, ip, bp, rho, ua, ub);
-        clip_ge(Q.x, iq, bq, rho, ua, ub);
-        clip_ge(T.x, it3, bt, rho, ua, ub);
-        if (!(ua <= ub + 1e-6f)) return 0;
-    }
-    // ---- umbra test ----
-    const float Rm = sr.R * 1.001f;
-    const float n0 = N.x, n1 = N.y;
-    if (n1 > 2.0f * Rm && n0 < 0.0f) {                          // front-facing for all samples, plane between light and surface point
-        // v_rcp_f32 is good to 1 ulp; the factors move the bounds outwards by 2e-6
-        const float ulo = -n0 * __builtin_amdgcn_rcpf(n1 + Rm) * 0.999998f, uhi = -n0 * __builtin_amdgcn_rcpf(n1 - Rm) * 1.000002f;
-        if (ulo > 2e-4f && uhi < 0.5f) {
-            const float margin = __builtin_fmaf(Rm, uhi, 3e-5f * sr.ext);      // fp32 evaluation error of an edge function is < 2e-6 * extent
-            const float e1 = fminf(__builtin_fmaf(ulo, P.y, P.x), __builtin_fmaf(uhi, P.y, P.x));
-            const float e2 = fminf(__builtin_fmaf(ulo, Q.y, Q.x), __builtin_fmaf(uhi, Q.y, Q.x));
-            const float e3 = fminf(__builtin_fmaf(ulo, T.y, T.x), __builtin_fmaf(uhi, T.y, T.x));
-            if (e1 > margin && e2 > margin && e3 > margin) {
-                // the crossing region must also be inside the root box (hits outside it are no hits: SpatialSubdivision.cs:652)
-                const f2 U = {ulo, uhi};
-                const f2 X = pk_fma(U, splat(sr.edx.y), splat(sr.edx.x)), Y = pk_fma(U, splat(sr.edy.y), splat(sr.edy.x)), Z = pk_fma(U, splat(sr.edz.y), splat(sr.edz.x));
-                if (fmaxf(fabsf(X.x), fabsf(X.y)) + margin < sr.hbx && fmaxf(fabsf(Y.x), fabsf(Y.y)) + margin < sr.hby &&
-                    fmaxf(fabsf(Z.x), fabsf(Z.y)) + margin < sr.hbz) return 2;
-            }
+    const float G0 = N.x, N1 = N.y;
+    // Triangle.IntersectRay is one-sided (dirDist >= 0 -> no hit, Plane.cs:60-61): a triangle with n.DL + R < 0 faces away from
+    // EVERY sample ray; G0 > 0: the surface point is in front of the plane (crossing at u < 0, i.e. rayFrac > 1); G0 + N1 + R < 0:
+    // every sample starts behind the plane
+    if (N1 < -sr.backface || G0 > sr.a0 || G0 + N1 + sr.R < -sr.a01) return 0;
+    const float g2 = G0 * G0, ag = fabsf(G0);
+    const float A1 = __builtin_fmaf(P.x, N1, -(G0 * P.y)), A2 = __builtin_fmaf(Q.x, N1, -(G0 * Q.y)), A3 = __builtin_fmaf(T.x, N1, -(G0 * T.y));
+    const float L1 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(P.x, P.x, g2)), L2 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(Q.x, Q.x, g2)),
+                L3 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(T.x, T.x, g2));
+    const float e1 = __builtin_fmaf(sr.c1, fabsf(P.x) + ag, sr.c0), e2 = __builtin_fmaf(sr.c1, fabsf(Q.x) + ag, sr.c0), e3 = __builtin_fmaf(sr.c1, fabsf(T.x) + ag, sr.c0);
+    // some direction of the ball inside every edge (each edge on its own)
+    if (fminf(fminf(A1 + L1 + e1, A2 + L2 + e2), A3 + L3 + e3) < 0.0f) return 0;
+    // ---- umbra: every direction of the ball inside every edge ----
+    if (fminf(fminf(A1 - L1 - e1, A2 - L2 - e2), A3 - L3 - e3) > 0.0f && N1 > 2.0f * sr.Rm + sr.a01 && G0 < -4.0f * sr.a0) {
+        // crossing parameters of all samples lie in [ulo, uhi] (v_rcp_f32 is good to 1 ulp; the factors move the bounds outwards)
+        const float ulo = -G0 * __builtin_amdgcn_rcpf(N1 + sr.Rm) * 0.999998f, uhi = -G0 * __builtin_amdgcn_rcpf(N1 - sr.Rm) * 1.000002f;
+        if (ulo > 1e-6f && uhi < 0.5f) {
+            // the crossing region must also be inside the root box (hits outside it are no hits: SpatialSubdivision.cs:652)
+            const float margin = __builtin_fmaf(sr.Rm, uhi, sr.umargin);
+            const f2 U = {ulo, uhi};
+            const f2 X = pk_fma(U, splat(sr.edx.y), splat(sr.edx.x)), Y = pk_fma(U, splat(sr.edy.y), splat(sr.edy.x)), Z = pk_fma(U, splat(sr.edz.y), splat(sr.edz.x));
+            if (fmaxf(fabsf(X.x), fabsf(X.y)) + margin < sr.hbx && fmaxf(fabsf(Y.x), fabsf(Y.y)) + margin < sr.hby &&
+                fmaxf(fabsf(Z.x), fabsf(Z.y)) + margin < sr.hbz) return 2;
         }
     }
     return 1;
@@ -480,7 +477,6 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         float ext = 0.0f;
         for (int a = 0; a < 3; ++a) ext = fmaxf(ext, (float)(sc.root.max[a] - sc.root.min[a]));
         const float pad = ext * 3.0517578125e-5f;                          // 2^-15 * extent (boxes carry 2^-16 already)
-        const float pad_tri = ext * 7.62939453125e-6f;                     // 2^-17 * extent: fp32 plane evaluation + fp64 hit-test slack
         const float ex = (float)(E.x - sc.root.centre[0]), ey = (float)(E.y - sc.root.centre[1]), ez = (float)(E.z - sc.root.centre[2]);
         const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
         // a zero direction component acts as a huge finite slope reciprocal: no inf - inf in the fused slab arithmetic
@@ -491,11 +487,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         const f2 OI01 = {-ex * ix, -ey * iy}, OI20 = {-ez * iz, -ex * ix}, OI12 = {-ey * iy, -ez * iz};
         const f2 RI01 = {-ix, -iy}, RI20 = {-iz, ix}, RI12 = {iy, iz};
         const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
-        ShaftRay sr;
-        sr.edx = (f2){ex, dx}; sr.edy = (f2){ey, dy}; sr.edz = (f2){ez, dz};
-        sr.R = R; sr.pad = pad_tri; sr.ext = ext;
-        sr.backface = R * 1.001f + 1e-6f * (fabsf(dx) + fabsf(dy) + fabsf(dz)) + 1e-30f;
-        sr.hbx = 0.5f * (float)(sc.root.max[0] - sc.root.min[0]); sr.hby = 0.5f * (float)(sc.root.max[1] - sc.root.min[1]); sr.hbz = 0.5f * (float)(sc.root.max[2] - sc.root.min[2]);
+        const ShaftRay sr = make_shaft_ray(sc, fc, E, lpos);
         const int nbits = sc.bnode_bits, qmax = (1 << (31 - nbits)) - 1;   // stack word = node | quantised u bound
         const float qinv = 1.0f / (float)qmax * 1.000001f;
         int32_t* out = cand + (size_t)slot_i * cap;
@@ -545,13 +537,12 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
             if (leafA < 0) break;
             while (leafA >= 0 && !truncated && !umbra) {
                 const int first = leafA & 0x0fffffff, cnt = (leafA >> 28) & 7;
-                const float ua = laA, ub = lbA;
                 leafA = leafB; laA = laB; lbA = lbB;
                 leafB = -1;
                 leaves++;
                 slabs += (uint32_t)cnt;
                 for (int q = 0; q < cnt; ++q) {
-                    const int touch = shaft_touches(sc.bslab[first + q], sr, ua, ub);
+                    const int touch = shaft_touches(sc.bslab[first + q], sr);
                     if (touch == 2) umbra = true;
                     if (touch) {
                         if (count < cap) { if (count >= 0) out[count] = first + q; count++; }
@@ -621,7 +612,6 @@ __global__ __launch_bounds__(256) void k_shaft_pkt(DevScene sc, FrameConst fc, c
     float ext = 0.0f;
     for (int a = 0; a < 3; ++a) ext = fmaxf(ext, (float)(sc.root.max[a] - sc.root.min[a]));
     const float pad = ext * 3.0517578125e-5f;                          // 2^-15 * extent (boxes carry 2^-16 already)
-    const float pad_tri = ext * 7.62939453125e-6f;                     // 2^-17 * extent
     const float ex = (float)(E.x - sc.root.centre[0]), ey = (float)(E.y - sc.root.centre[1]), ez = (float)(E.z - sc.root.centre[2]);
     const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
     const float ix = slab_inv(dx), iy = slab_inv(dy), iz = slab_inv(dz);
@@ -629,11 +619,7 @@ __global__ __launch_bounds__(256) void k_shaft_pkt(DevScene sc, FrameConst fc, c
     const f2 OI01 = {-ex * ix, -ey * iy}, OI20 = {-ez * iz, -ex * ix}, OI12 = {-ey * iy, -ez * iz};
     const f2 RI01 = {-ix, -iy}, RI20 = {-iz, ix}, RI12 = {iy, iz};
     const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
-    ShaftRay sr;
-    sr.edx = (f2){ex, dx}; sr.edy = (f2){ey, dy}; sr.edz = (f2){ez, dz};
-    sr.R = R; sr.pad = pad_tri; sr.ext = ext;
-    sr.backface = R * 1.001f + 1e-6f * (fabsf(dx) + fabsf(dy) + fabsf(dz)) + 1e-30f;
-    sr.hbx = 0.5f * (float)(sc.root.max[0] - sc.root.min[0]); sr.hby = 0.5f * (float)(sc.root.max[1] - sc.root.min[1]); sr.hbz = 0.5f * (float)(sc.root.max[2] - sc.root.min[2]);
+    const ShaftRay sr = make_shaft_ray(sc, fc, E, lpos);
     int32_t* out = cand + (size_t)slot_i * cap;
     int count = 0;
     bool truncated = false, umbra = false;
@@ -669,14 +655,13 @@ __global__ __launch_bounds__(256) void k_shaft_pkt(DevScene sc, FrameConst fc, c
             const bool c0 = (t == 0) == first0;
             const int cn = c0 ? n.n0 : n.n1, cc = c0 ? n.c0 : n.c1;
             if (cn > 0 && __ballot((c0 ? h0 : h1) && !done) != 0ull) {
-                const float ua = c0 ? a0 : a1, ub = c0 ? b0 : b1;
                 const bool hc = c0 ? h0 : h1;
                 leaves++;
                 slabs += (uint32_t)cn;
                 for (int q = 0; q < cn; ++q) {
                     const TriSlab s = sc.bslab[cc + q];               // scalar load
                     if (hc && !done) {
-                        const int touch = shaft_touches(s, sr, ua, ub);
+                        const int touch = shaft_touches(s, sr);
                         if (touch == 2) umbra = true;
                         if (touch) {
                             if (count < cap) { out[count] = cc + q; count++; }
