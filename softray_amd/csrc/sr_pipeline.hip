@@ -414,40 +414,42 @@ __device__ __forceinline__ ShaftRay make_shaft_ray(const DevScene& sc, const Fra
     return sr;
 }
 
-// returns 0: no sample ray can hit the triangle; 1: candidate; 2: UMBRA
-__device__ __forceinline__ int shaft_touches(const TriSlab s, const ShaftRay& sr) {
+// returns 0: no sample ray can hit the triangle; 1: candidate; 2: UMBRA.  Straight-line code (the kernels that call it are
+// bound by instruction issue, scalar bookkeeping of nested branches included); `want`: lanes whose verdict is looked at.
+__device__ __forceinline__ int shaft_touches(const TriSlab s, const ShaftRay& sr, bool want) {
     // (f0, f1) of the plane and the three edge planes along the centre ray, two lanes per packed FMA
     f2 cn = {-s.d, 0.0f}, c1 = {-s.c1, 0.0f}, c2 = {-s.c2, 0.0f}, c3 = {-s.c3, 0.0f};
     const f2 N = pk_fma(splat(s.n[0]), sr.edx, pk_fma(splat(s.n[1]), sr.edy, pk_fma(splat(s.n[2]), sr.edz, cn)));
-    const f2 P = pk_fma(splat(s.m1[0]), sr.edx, pk_fma(splat(s.m1[1]), sr.edy, pk_fma(splat(s.m1[2]), sr.edz, c1)));
-    const f2 Q = pk_fma(splat(s.m2[0]), sr.edx, pk_fma(splat(s.m2[1]), sr.edy, pk_fma(splat(s.m2[2]), sr.edz, c2)));
-    const f2 T = pk_fma(splat(s.m3[0]), sr.edx, pk_fma(splat(s.m3[1]), sr.edy, pk_fma(splat(s.m3[2]), sr.edz, c3)));
     const float G0 = N.x, N1 = N.y;
     // Triangle.IntersectRay is one-sided (dirDist >= 0 -> no hit, Plane.cs:60-61): a triangle with n.DL + R < 0 faces away from
     // EVERY sample ray; G0 > 0: the surface point is in front of the plane (crossing at u < 0, i.e. rayFrac > 1); G0 + N1 + R < 0:
     // every sample starts behind the plane
-    if (N1 < -sr.backface || G0 > sr.a0 || G0 + N1 + sr.R < -sr.a01) return 0;
+    const bool plane_ok = want && !(N1 < -sr.backface) && !(G0 > sr.a0) && !(G0 + N1 + sr.R < -sr.a01);
+    if (__ballot(plane_ok) == 0ull) return 0;                          // (wave-level: nobody is left)
+    const f2 P = pk_fma(splat(s.m1[0]), sr.edx, pk_fma(splat(s.m1[1]), sr.edy, pk_fma(splat(s.m1[2]), sr.edz, c1)));
+    const f2 Q = pk_fma(splat(s.m2[0]), sr.edx, pk_fma(splat(s.m2[1]), sr.edy, pk_fma(splat(s.m2[2]), sr.edz, c2)));
+    const f2 T = pk_fma(splat(s.m3[0]), sr.edx, pk_fma(splat(s.m3[1]), sr.edy, pk_fma(splat(s.m3[2]), sr.edz, c3)));
     const float g2 = G0 * G0, ag = fabsf(G0);
     const float A1 = __builtin_fmaf(P.x, N1, -(G0 * P.y)), A2 = __builtin_fmaf(Q.x, N1, -(G0 * Q.y)), A3 = __builtin_fmaf(T.x, N1, -(G0 * T.y));
     const float L1 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(P.x, P.x, g2)), L2 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(Q.x, Q.x, g2)),
                 L3 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(T.x, T.x, g2));
     const float e1 = __builtin_fmaf(sr.c1, fabsf(P.x) + ag, sr.c0), e2 = __builtin_fmaf(sr.c1, fabsf(Q.x) + ag, sr.c0), e3 = __builtin_fmaf(sr.c1, fabsf(T.x) + ag, sr.c0);
     // some direction of the ball inside every edge (each edge on its own)
-    if (fminf(fminf(A1 + L1 + e1, A2 + L2 + e2), A3 + L3 + e3) < 0.0f) return 0;
+    const bool cand = plane_ok && !(fminf(fminf(A1 + L1 + e1, A2 + L2 + e2), A3 + L3 + e3) < 0.0f);
     // ---- umbra: every direction of the ball inside every edge ----
-    if (fminf(fminf(A1 - L1 - e1, A2 - L2 - e2), A3 - L3 - e3) > 0.0f && N1 > 2.0f * sr.Rm + sr.a01 && G0 < -4.0f * sr.a0) {
+    const bool pre = cand && fminf(fminf(A1 - L1 - e1, A2 - L2 - e2), A3 - L3 - e3) > 0.0f && N1 > 2.0f * sr.Rm + sr.a01 && G0 < -4.0f * sr.a0;
+    bool umbra = false;
+    if (__ballot(pre) != 0ull) {
         // crossing parameters of all samples lie in [ulo, uhi] (v_rcp_f32 is good to 1 ulp; the factors move the bounds outwards)
         const float ulo = -G0 * __builtin_amdgcn_rcpf(N1 + sr.Rm) * 0.999998f, uhi = -G0 * __builtin_amdgcn_rcpf(N1 - sr.Rm) * 1.000002f;
-        if (ulo > 1e-6f && uhi < 0.5f) {
-            // the crossing region must also be inside the root box (hits outside it are no hits: SpatialSubdivision.cs:652)
-            const float margin = __builtin_fmaf(sr.Rm, uhi, sr.umargin);
-            const f2 U = {ulo, uhi};
-            const f2 X = pk_fma(U, splat(sr.edx.y), splat(sr.edx.x)), Y = pk_fma(U, splat(sr.edy.y), splat(sr.edy.x)), Z = pk_fma(U, splat(sr.edz.y), splat(sr.edz.x));
-            if (fmaxf(fabsf(X.x), fabsf(X.y)) + margin < sr.hbx && fmaxf(fabsf(Y.x), fabsf(Y.y)) + margin < sr.hby &&
-                fmaxf(fabsf(Z.x), fabsf(Z.y)) + margin < sr.hbz) return 2;
-        }
+        // the crossing region must also be inside the root box (hits outside it are no hits: SpatialSubdivision.cs:652)
+        const float margin = __builtin_fmaf(sr.Rm, uhi, sr.umargin);
+        const f2 U = {ulo, uhi};
+        const f2 X = pk_fma(U, splat(sr.edx.y), splat(sr.edx.x)), Y = pk_fma(U, splat(sr.edy.y), splat(sr.edy.x)), Z = pk_fma(U, splat(sr.edz.y), splat(sr.edz.x));
+        umbra = pre && ulo > 1e-6f && uhi < 0.5f && fmaxf(fabsf(X.x), fabsf(X.y)) + margin < sr.hbx && fmaxf(fabsf(Y.x), fabsf(Y.y)) + margin < sr.hby &&
+                fmaxf(fabsf(Z.x), fabsf(Z.y)) + margin < sr.hbz;
     }
-    return 1;
+    return umbra ? 2 : (cand ? 1 : 0);
 }
 
 template <bool STATS>
@@ -542,7 +544,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                 leaves++;
                 slabs += (uint32_t)cnt;
                 for (int q = 0; q < cnt; ++q) {
-                    const int touch = shaft_touches(sc.bslab[first + q], sr);
+                    const int touch = shaft_touches(sc.bslab[first + q], sr, true);
                     if (touch == 2) umbra = true;
                     if (touch) {
                         if (count < cap) { if (count >= 0) out[count] = first + q; count++; }
@@ -660,15 +662,14 @@ __global__ __launch_bounds__(256) void k_shaft_pkt(DevScene sc, FrameConst fc, c
                 slabs += (uint32_t)cn;
                 for (int q = 0; q < cn; ++q) {
                     const TriSlab s = sc.bslab[cc + q];               // scalar load
-                    if (hc && !done) {
-                        const int touch = shaft_touches(s, sr);
-                        if (touch == 2) umbra = true;
-                        if (touch) {
-                            if (count < cap) { out[count] = cc + q; count++; }
-                            else truncated = true;
-                        }
-                        done = umbra || truncated;
-                    }
+                    const bool live_q = hc && !done;
+                    const int touch = shaft_touches(s, sr, live_q);
+                    const bool take = live_q && touch != 0, room = count < cap;
+                    if (take && room) out[count] = cc + q;
+                    count += (take && room) ? 1 : 0;
+                    truncated = truncated || (take && !room);
+                    umbra = umbra || (live_q && touch == 2);
+                    done = done || truncated || umbra;
                 }
             }
         }
