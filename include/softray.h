@@ -165,6 +165,8 @@ int  sr_build(sr_scene*, uint32_t modes, int32_t max_depth, int32_t max_per_leaf
 #define SR_BUILD_ON_DEVICE 0x100u
 /* out = TreeDepth, NumNodes, NumLeafNodes, NumInternalNodes (SpatialSubdivision.cs:317-335) */
 int  sr_tree_stats(const sr_scene*, int32_t out[4]);
+/* the library's own BVH: out = depth, inner nodes, triangles, 1 if it was built on the device */
+int  sr_bvh_stats(const sr_scene*, int64_t out[4]);
 
 /* Renderer.Render() for one Instance, raytrace path (Renderer.cs:701-778 -> RaytraceGeometry :1501 ->
  * RaytraceBlock :1690).  pixels = caller-owned int[W*H] ARGB, row-major pixels[row*W+col]

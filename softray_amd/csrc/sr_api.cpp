@@ -603,6 +603,13 @@ int sr_tree_stats(const sr_scene* s, int32_t out[4]) {
     return SR_OK;
 }
 
+int sr_bvh_stats(const sr_scene* s, int64_t out[4]) {
+    if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
+    if (!s->bvh.built) return fail(SR_ERR_NOT_BUILT, "BVH not built");
+    out[0] = s->bvh.depth; out[1] = (int64_t)(s->bvh_on_device ? s->bvh_num_nodes : s->bvh.nodes.size()); out[2] = (int64_t)s->tri_recs.size(); out[3] = s->bvh_on_device ? 1 : 0;
+    return SR_OK;
+}
+
 int64_t sr_frame_pixel_count(const sr_frame* f) {
     if (!f || f->width <= 0 || f->height <= 0) return 0;
     if (f->strip_count <= 0) return (int64_t)f->width * f->height;

@@ -81,6 +81,12 @@ class GpuScene:
         _check(_lib.lib().sr_tree_stats(self._h, _p(out)))
         return tuple(int(x) for x in out)
 
+    def bvh_stats(self):
+        """(depth, inner nodes, triangles, built on device) of the library's own BVH."""
+        out = np.zeros(4, dtype=np.int64)
+        _check(_lib.lib().sr_bvh_stats(self._h, _p(out)))
+        return tuple(int(x) for x in out)
+
     # ---- Render() ----
     @staticmethod
     def pixel_count(frame):
