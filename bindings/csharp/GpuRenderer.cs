@@ -1,61 +1,96 @@
 // GpuRenderer.cs -- P/Invoke binding of libsoftray_hip.so (include/softray.h) for the reference's C# host.
 //
-// SOURCE ONLY: the build image has no C# toolchain (no dotnet / mono / csc), so this file is compile-checked by
-// nobody here; it is the binding a maintainer of voidstar69/softray adds to Engine3D (see INTEGRATION.md).  The
-// struct layouts mirror include/softray.h field for field (LayoutKind.Sequential, natural alignment).
+// SOURCE ONLY: the build image has no C# toolchain (no dotnet / mono / csc), so nobody compiles this file here; it is the
+// binding a maintainer of voidstar69/softray adds to Engine3D (INTEGRATION.md shows where Renderer.cs calls it).  What WAS
+// checked: every member of the reference it touches, against the reference sources --
+//   Model.Triangles is ICollection<Triangle> (enumerated, never indexed), Model.Vertices[i].pos, Triangle.vertexIndex1..3,
+//   Triangle.diffuseMaterial, Model.Min / Max                                  Engine3D/Model.cs:16,44-46,53,137-138,192-194
+//   Surface.PackColorAndAlpha(Color, double)                                    Engine3D/Surface.cs:131
+//   Instance.Position, Matrix this[row, col]                                    Engine3D/Instance.cs:47, Matrix.cs:16
+//   GeometryCollection.Count / this[int]                                        Engine3D/Raytrace/GeometryCollection.cs:16,24
+//   Raytrace.Triangle.Vertex1..3, .Color (uint)                                 Engine3D/Raytrace/Triangle.cs:59-67
+//   Plane.Normal, Plane.DistanceToOrigin                                        Engine3D/Raytrace/Plane.cs:40,52
+// and the FIVE accessors the reference lacks and INTEGRATION.md adds (private state the native side needs):
+//   Sphere.Center, Sphere.Radius, Sphere.PackedColor, Plane.PackedColor, Instance.Transform / Instance.InverseTransform.
+// The struct layouts mirror include/softray.h field for field (LayoutKind.Sequential, natural alignment); the byte offsets in
+// the comments are the ones the header asserts at compile time (tests/test_abi.py compares them with this file).
 //
-// Two ways to use it:
-//   1. patch Renderer.RaytraceGeometry (Engine3D/Renderer.cs:1655-1686): replace the Task fan-out over RaytraceBlock
-//      with SoftrayHip.RenderInto(this, instance)   -- the drop-in; every public field keeps its meaning;
-//   2. use GpuRenderer below as a stand-alone class with the same public surface.
+// There is one entry point per Renderer call site: Upload (PreCalculate), SetExtraGeometry (ExtraGeometryToRaytrace),
+// Render (RaytraceGeometry), PostProcess / AntiAlias (the two surface passes of Render()), Dispose.
 using System;
 using System.Runtime.InteropServices;
 
 namespace Engine3D.Hip
 {
     [StructLayout(LayoutKind.Sequential)]
-    public struct SrPrim
+    public struct SrPrim                     // sr_prim, 80 bytes
     {
-        public int kind;                 // 0 Sphere, 1 Plane, 2 Triangle
-        public uint argb;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 9)] public double[] p;
+        /* @0 */ public int kind;            // 0 Sphere {centre, radius}, 2 Triangle {v1, v2, v3}, 3 Plane {unit normal, originDist}
+        /* @4 */ public uint argb;
+        /* @8 */ [MarshalAs(UnmanagedType.ByValArray, SizeConst = 9)] public double[] p;
     }
 
     [StructLayout(LayoutKind.Sequential)]
-    public struct SrFrame
+    public struct SrFrame                    // sr_frame, 368 bytes
     {
-        public int width, height, start_row, end_row, sub_pixel_res;
-        public uint background_argb, flags;
-        public int random_seed, shadow_samples, trace_mode, strip_rows, strip_count, strip_index, max_bounces, concurrency, reserved0;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 12)] public double[] transform;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 12)] public double[] inv_transform;
-        public double position_z, fov_depth, focal_depth, focal_blur_strength, ambient, shininess;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public double[] light_dir_view;
-        [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public double[] light_pos_view;
-        public double reflectivity;
-        public IntPtr area_light_offsets;   // double[shadow_samples][3] produced with the REAL System.Random, or IntPtr.Zero
+        /* @0   */ public int width;
+        /* @4   */ public int height;
+        /* @8   */ public int start_row;
+        /* @12  */ public int end_row;
+        /* @16  */ public int sub_pixel_res;
+        /* @20  */ public uint background_argb;
+        /* @24  */ public uint flags;
+        /* @28  */ public int random_seed;
+        /* @32  */ public int shadow_samples;
+        /* @36  */ public int trace_mode;
+        /* @40  */ public int strip_rows;
+        /* @44  */ public int strip_count;
+        /* @48  */ public int strip_index;
+        /* @52  */ public int max_bounces;
+        /* @56  */ public int concurrency;
+        /* @60  */ public int reserved0;
+        /* @64  */ [MarshalAs(UnmanagedType.ByValArray, SizeConst = 12)] public double[] transform;
+        /* @160 */ [MarshalAs(UnmanagedType.ByValArray, SizeConst = 12)] public double[] inv_transform;
+        /* @256 */ public double position_z;
+        /* @264 */ public double fov_depth;
+        /* @272 */ public double focal_depth;
+        /* @280 */ public double focal_blur_strength;
+        /* @288 */ public double ambient;
+        /* @296 */ public double shininess;
+        /* @304 */ [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public double[] light_dir_view;
+        /* @328 */ [MarshalAs(UnmanagedType.ByValArray, SizeConst = 3)] public double[] light_pos_view;
+        /* @352 */ public double reflectivity;
+        /* @360 */ public IntPtr area_light_offsets;   // double[shadow_samples][3] made with the REAL System.Random, or IntPtr.Zero
     }
+    // ByValArray fields of a struct passed by `ref` are marshalled inline (the marshaller copies the managed arrays into the
+    // 368-byte native image and back): all five arrays must be non-null and exactly SizeConst long, which Render() guarantees.
 
     internal static class Native
     {
         const string Lib = "softray_hip";
         [DllImport(Lib)] public static extern int sr_create(int device, out IntPtr scene);
+        [DllImport(Lib)] public static extern int sr_create_multi([In] int[] devices, int n, out IntPtr scene);
         [DllImport(Lib)] public static extern void sr_destroy(IntPtr scene);
         [DllImport(Lib)] public static extern int sr_set_triangles(IntPtr scene, double[] v9, uint[] argb, long n, double[] boxMin, double[] boxMax);
         [DllImport(Lib)] public static extern int sr_set_extra_geometry(IntPtr scene, [In] SrPrim[] prims, int n);
         [DllImport(Lib)] public static extern int sr_build(IntPtr scene, uint modes, int maxDepth, int maxPerLeaf);
         [DllImport(Lib)] public static extern int sr_tree_stats(IntPtr scene, [Out] int[] out4);
         [DllImport(Lib)] public static extern int sr_render(IntPtr scene, ref SrFrame frame, [In, Out] int[] pixels, [Out] ulong[] stats4);
+        [DllImport(Lib)] public static extern int sr_reset_shadow_cache(IntPtr scene);
         [DllImport(Lib)] public static extern int sr_load_3ds(IntPtr scene, byte[] data, UIntPtr len);
         [DllImport(Lib)] public static extern int sr_post_process(IntPtr scene, [In, Out] int[] pixels, long count, int style, uint backgroundColor);
         [DllImport(Lib)] public static extern int sr_anti_alias(IntPtr scene, [In] int[] src, int dstWidth, int dstHeight, int resolution, [In, Out] int[] dst);
         [DllImport(Lib)] public static extern IntPtr sr_last_error();
+        [DllImport(Lib)] public static extern int sr_abi_version();
         public static string LastError() { return Marshal.PtrToStringAnsi(sr_last_error()); }
 
         public const int SR_ERR_INVALID_ARG = -1, SR_ERR_OUT_OF_RANGE = -2, SR_ERR_NO_MODEL = -3, SR_ERR_FORMAT = -8;
-        public static void Check(int rc)
+        public const int AbiVersion = 3;
+
+        /// <param name="renderCall">true only for sr_render: Render() without a model draws nothing and returns (Renderer.cs:736-739)</param>
+        public static void Check(int rc, bool renderCall = false)
         {
-            if (rc == 0 || rc == SR_ERR_NO_MODEL) return;                       // no model: Render() returns silently (Renderer.cs:736-739)
+            if (rc == 0 || (renderCall && rc == SR_ERR_NO_MODEL)) return;
             string msg = LastError();
             switch (rc)
             {
@@ -67,37 +102,99 @@ namespace Engine3D.Hip
         }
     }
 
-    /// <summary>What Renderer.RaytraceGeometry hands to the device instead of the TPL fan-out over RaytraceBlock.</summary>
+    /// <summary>What Renderer hands to the device(s) instead of the TPL fan-out over RaytraceBlock (Renderer.cs:1655-1686).</summary>
     public sealed class SoftrayHip : IDisposable
     {
         public const uint F_SHADING = 1, F_SHADOWS = 2, F_FOCAL_BLUR = 4, F_POINT_LIGHT = 8, F_SPECULAR = 16, F_STATIC_SHADOWS = 32;
         public const int MODE_REF_TREE = 0, MODE_BRUTE = 1, MODE_BVH = 2;
         IntPtr scene;
-        Model uploaded;
-        double[] areaLightOffsets;       // generated once with new Random(rayTraceRandomSeed): ShadowMethod.cs:63-73
+        Model uploaded;                  // the model whose triangles the scene holds
+        uint builtModes;                 // structures built for `uploaded` (bit 1 << mode)
+        int offsetsSeed;                 // seed areaLightOffsets was generated with
+        double[] areaLightOffsets;       // new Random(rayTraceRandomSeed): ShadowMethod.cs:63-73
         GCHandle offsetsPin;
 
-        public SoftrayHip(int device = 0) { Native.Check(Native.sr_create(device, out scene)); }
+        /// <summary>One MI355X.</summary>
+        public SoftrayHip(int device = 0)
+        {
+            if (Native.sr_abi_version() != Native.AbiVersion) throw new InvalidOperationException("libsoftray_hip: ABI version mismatch");
+            Native.Check(Native.sr_create(device, out scene));
+        }
 
-        /// PreCalculate(): MakeRayTracableGeometry_simple (Renderer.cs:1452-1469) flattened + sr_build
+        /// <summary>A whole node from this one process: the frame's rows are split into interleaved 16-row strips over
+        /// `devices` inside the library and copied straight into the caller's pixels (sr_create_multi).</summary>
+        public SoftrayHip(int[] devices)
+        {
+            if (Native.sr_abi_version() != Native.AbiVersion) throw new InvalidOperationException("libsoftray_hip: ABI version mismatch");
+            Native.Check(Native.sr_create_multi(devices, devices.Length, out scene));
+        }
+
+        /// PreCalculate() (Renderer.cs:673-699): MakeRayTracableGeometry_simple (:1452-1469) flattened, then the structure for
+        /// `mode`.  Like the reference (geometry_* == null guards, :684-696) nothing is rebuilt while the model and the mode
+        /// stay the same -- Renderer.Render() calls PreCalculate() every frame.
         public void Upload(Model model, int mode)
         {
             if (!ReferenceEquals(model, uploaded))
             {
                 int n = model.Triangles.Count;
                 var v9 = new double[n * 9]; var argb = new uint[n];
-                for (int i = 0; i < n; i++)
+                int i = 0;
+                foreach (Triangle tri in model.Triangles)                                            // triIndex = enumeration order, :1458-1467
                 {
-                    Triangle tri = model.Triangles[i];
-                    Vector[] v = { model.Vertices[tri.vertexIndex1].pos, model.Vertices[tri.vertexIndex2].pos, model.Vertices[tri.vertexIndex3].pos };
-                    for (int k = 0; k < 3; k++) { v9[9 * i + 3 * k] = v[k].x; v9[9 * i + 3 * k + 1] = v[k].y; v9[9 * i + 3 * k + 2] = v[k].z; }
-                    argb[i] = Surface.PackColorAndAlpha(tri.diffuseMaterial, 1.0);                   // Renderer.cs:1463
+                    Vector v1 = model.Vertices[tri.vertexIndex1].pos, v2 = model.Vertices[tri.vertexIndex2].pos, v3 = model.Vertices[tri.vertexIndex3].pos;
+                    v9[9 * i + 0] = v1.x; v9[9 * i + 1] = v1.y; v9[9 * i + 2] = v1.z;
+                    v9[9 * i + 3] = v2.x; v9[9 * i + 4] = v2.y; v9[9 * i + 5] = v2.z;
+                    v9[9 * i + 6] = v3.x; v9[9 * i + 7] = v3.y; v9[9 * i + 8] = v3.z;
+                    argb[i] = Surface.PackColorAndAlpha(tri.diffuseMaterial, 1.0);                   // :1463
+                    i++;
                 }
                 Native.Check(Native.sr_set_triangles(scene, v9, argb, n,
-                    new[] { model.Min.x, model.Min.y, model.Min.z }, new[] { model.Max.x, model.Max.y, model.Max.z }));
+                    new[] { model.Min.x, model.Min.y, model.Min.z }, new[] { model.Max.x, model.Max.y, model.Max.z }));   // :1487
                 uploaded = model;
+                builtModes = 0;
             }
-            if (mode != MODE_BRUTE) Native.Check(Native.sr_build(scene, 1u << mode, 0, 0));         // SpatialSubdivision defaults 15 / 25
+            uint bit = 1u << mode;
+            if (mode != MODE_BRUTE && (builtModes & bit) == 0)
+            {
+                Native.Check(Native.sr_build(scene, bit, 0, 0));                                     // SpatialSubdivision defaults 15 / 25
+                builtModes |= bit;
+            }
+        }
+
+        /// ExtraGeometryToRaytrace (Renderer.cs:460, 1545-1549): the collection is scanned first to last BEFORE the model, with
+        /// a strict '<' on rayFrac (GeometryCollection.cs:44-69) -- the order is kept.  Call it whenever the collection changes
+        /// and before the reference appends the model's root to it (:1547).  Uses the accessors INTEGRATION.md adds.
+        public void SetExtraGeometry(GeometryCollection extras)
+        {
+            int n = extras == null ? 0 : extras.Count;
+            var prims = new SrPrim[Math.Max(n, 1)];
+            for (int i = 0; i < n; i++)
+            {
+                var prim = new SrPrim { p = new double[9] };
+                IRayIntersectable g = extras[i];
+                var sphere = g as Sphere; var plane = g as Plane; var tri = g as Raytrace.Triangle;
+                if (sphere != null)
+                {
+                    prim.kind = 0; prim.argb = sphere.PackedColor;                                    // Color.ToARGB(), Sphere.cs:51-55
+                    prim.p[0] = sphere.Center.x; prim.p[1] = sphere.Center.y; prim.p[2] = sphere.Center.z; prim.p[3] = sphere.Radius;
+                }
+                else if (plane != null)
+                {
+                    prim.kind = 3; prim.argb = plane.PackedColor;                                     // the stored unit normal and originDist, verbatim
+                    prim.p[0] = plane.Normal.x; prim.p[1] = plane.Normal.y; prim.p[2] = plane.Normal.z; prim.p[3] = plane.DistanceToOrigin;
+                }
+                else if (tri != null)
+                {
+                    prim.kind = 2; prim.argb = tri.Color;
+                    prim.p[0] = tri.Vertex1.x; prim.p[1] = tri.Vertex1.y; prim.p[2] = tri.Vertex1.z;
+                    prim.p[3] = tri.Vertex2.x; prim.p[4] = tri.Vertex2.y; prim.p[5] = tri.Vertex2.z;
+                    prim.p[6] = tri.Vertex3.x; prim.p[7] = tri.Vertex3.y; prim.p[8] = tri.Vertex3.z;
+                }
+                else throw new NotSupportedException("ExtraGeometryToRaytrace holds a " + g.GetType().Name + ": only Sphere, Plane and Triangle have a device form");
+                prims[i] = prim;
+            }
+            if (n == 0) prims[0].p = new double[9];
+            Native.Check(Native.sr_set_extra_geometry(scene, prims, n));
         }
 
         /// The host half of RaytraceGeometry (Renderer.cs:1510-1528, 1652-1653): copy public fields into sr_frame.
@@ -106,17 +203,20 @@ namespace Engine3D.Hip
                            double fieldOfViewDepth, double focalDepth, double focalBlurStrength, double ambient, double shininess,
                            Vector lightDirView, Vector lightPosView, ulong[] stats4, int concurrency = 4)
         {
-            if (areaLightOffsets == null)
+            if (areaLightOffsets == null || offsetsSeed != randomSeed)
             {
                 var random = new Random(randomSeed);                                                   // Renderer.cs:1624
-                areaLightOffsets = new double[300];
-                for (int i = 0; i < 100; i++)
+                var table = new double[300];
+                for (int i = 0; i < 100; i++)                                                          // softShadowQuality, ShadowMethod.cs:9
                 {
                     var o = new Vector(random.NextDouble() * 2 - 1, random.NextDouble() * 2 - 1, random.NextDouble() * 2 - 1);
                     o.Normalise(); o *= 0.2;
-                    areaLightOffsets[3 * i] = o.x; areaLightOffsets[3 * i + 1] = o.y; areaLightOffsets[3 * i + 2] = o.z;
+                    table[3 * i] = o.x; table[3 * i + 1] = o.y; table[3 * i + 2] = o.z;
                 }
+                if (offsetsPin.IsAllocated) offsetsPin.Free();
+                areaLightOffsets = table;
                 offsetsPin = GCHandle.Alloc(areaLightOffsets, GCHandleType.Pinned);
+                offsetsSeed = randomSeed;
             }
             var f = new SrFrame
             {
@@ -131,8 +231,11 @@ namespace Engine3D.Hip
                 area_light_offsets = offsetsPin.AddrOfPinnedObject()
             };
             for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { f.transform[4 * r + c] = transform[r, c]; f.inv_transform[4 * r + c] = inverseTransform[r, c]; }
-            Native.Check(Native.sr_render(scene, ref f, pixels, stats4));      // blocking; `pixels` is only touched during the call
+            Native.Check(Native.sr_render(scene, ref f, pixels, stats4), renderCall: true);   // blocking; `pixels` is only touched during the call
         }
+
+        /// A new Renderer starts with an empty static shadow cache (ShadowMethod.cs:75-83)
+        public void ResetShadowCache() { Native.Check(Native.sr_reset_shadow_cache(scene)); }
 
         /// PostProcessImage's colour functions (Renderer.cs:819-865): style = (int)Renderer.Style for Standard..DepthBanded.
         public void PostProcess(int[] pixels, int style, uint backgroundColor)

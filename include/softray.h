@@ -92,7 +92,10 @@ enum {
 typedef struct {
     int32_t  kind;      /* 0 Sphere {centre xyz, radius}          Raytrace/Sphere.cs:26-33
                            1 Plane  {point xyz, normal xyz}       Raytrace/Plane.cs:22-29
-                           2 Triangle {v1, v2, v3}                Raytrace/Triangle.cs:29-57            */
+                           2 Triangle {v1, v2, v3}                Raytrace/Triangle.cs:29-57
+                           3 Plane as the object holds it {Plane.Normal xyz (unit), Plane.DistanceToOrigin}
+                             (Plane.cs:40-62): what a host passes for an EXISTING Plane -- kind 1 would
+                             normalise and project again and could differ in the last bit              */
     uint32_t argb;      /* Color.ToARGB() of the primitive's Color                                      */
     double   p[9];
 } sr_prim;
@@ -139,11 +142,38 @@ typedef struct {
                                         real System.Random); NULL => derived from random_seed             */
 } sr_frame;
 
+/* Layout contract of the two structs that cross the boundary by value / by reference (x86-64 SysV and Windows x64 agree): the
+ * C# shim mirrors it with [StructLayout(LayoutKind.Sequential)] (bindings/csharp/GpuRenderer.cs carries the same offsets
+ * as comments), softray_amd/_lib.py with ctypes; tests/test_abi.py checks the three against each other. */
+#ifdef __cplusplus
+#define SR_LAYOUT_ASSERT(cond, msg) static_assert(cond, msg)
+#else
+#define SR_LAYOUT_ASSERT(cond, msg) _Static_assert(cond, msg)
+#endif
+SR_LAYOUT_ASSERT(sizeof(sr_prim) == 80, "sr_prim is 80 bytes: kind@0 argb@4 p@8");
+SR_LAYOUT_ASSERT(offsetof(sr_prim, p) == 8, "sr_prim.p@8");
+SR_LAYOUT_ASSERT(sizeof(sr_frame) == 368, "sr_frame is 368 bytes");
+SR_LAYOUT_ASSERT(offsetof(sr_frame, flags) == 24 && offsetof(sr_frame, trace_mode) == 36 && offsetof(sr_frame, strip_rows) == 40 &&
+                 offsetof(sr_frame, max_bounces) == 52 && offsetof(sr_frame, concurrency) == 56, "sr_frame int block");
+SR_LAYOUT_ASSERT(offsetof(sr_frame, transform) == 64 && offsetof(sr_frame, inv_transform) == 160 && offsetof(sr_frame, position_z) == 256 &&
+                 offsetof(sr_frame, fov_depth) == 264 && offsetof(sr_frame, focal_depth) == 272 && offsetof(sr_frame, ambient) == 288 &&
+                 offsetof(sr_frame, light_dir_view) == 304 && offsetof(sr_frame, light_pos_view) == 328 &&
+                 offsetof(sr_frame, reflectivity) == 352 && offsetof(sr_frame, area_light_offsets) == 360, "sr_frame double block");
+
 typedef struct sr_scene sr_scene;    /* one per Renderer; freed by Dispose() (Renderer.cs:236)           */
 
 /* device >= 0: HIP device ordinal.  device == -1: host-only scene (sr_set_*, sr_build, sr_tree_stats,
  * sr_load_3ds work; every compute call returns SR_ERR_NO_DEVICE). */
 int  sr_create(int32_t device, sr_scene** out);
+/* One scene over n HIP devices of this process (SURVEY 8b `sr_create(device_count, ...)`, 8e): the model and its trees are
+ * replicated (sr_set_* / sr_build / sr_load_3ds act on every device; host builds run once), sr_render / sr_render_device split
+ * the frame's rows into interleaved 16-row strips -- device g renders the strips s with s % n == g, all devices concurrently --
+ * and the strips are copied straight into the caller's surface (device -> host over each device's own link, or peer-to-peer over
+ * xGMI into the device surface, which lives on devices[0]).  The pixels do not depend on n (no reduction, no RNG).  This is
+ * how a single-process host -- the C# Renderer -- uses a whole node.  Frames that need one global order (SR_F_STATIC_SHADOWS)
+ * or that already carry strip_* fields are rendered by devices[0] alone.  The same ordinal may appear more than once. */
+int  sr_create_multi(const int32_t* devices, int32_t n, sr_scene** out);
+int32_t sr_device_count(const sr_scene*);
 void sr_destroy(sr_scene*);
 
 /* MakeRayTracableGeometry_simple (Renderer.cs:1452-1469): v9 = [n][3 vertices][xyz] in model space
@@ -274,7 +304,7 @@ enum {
 };
 int  sr_debug_set(sr_scene*, int32_t key, int64_t value);
 
-/* Diagnostics only: the pipeline's device counters after the last row band of the last frame
+/* Diagnostics only: the pipeline's device counters of the last frame, summed over its concurrent part-frame pipelines (last row band of each)
  * {hit points queued, per-lane shadow work head, hit points that needed the long (round-2) candidate list,
  *  hit points sent to the exact per-lane fallback, fallback work head, 0, 0, 0}. */
 int  sr_debug_counters(sr_scene*, uint32_t out[8]);

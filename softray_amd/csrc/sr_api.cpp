@@ -60,6 +60,10 @@ struct DBuf {
 
 struct sr_scene {
     int device = -1;
+    // sr_create_multi: this scene only dispatches to one complete scene per device (the model is replicated, a frame is split
+    // into interleaved 16-row strips); empty for an ordinary scene
+    std::vector<sr_scene*> parts;
+    DBuf d_gather;                         // (dispatcher) unused; parts render into their own d_pixels
     // host copies (what Renderer keeps between frames)
     std::vector<double>   v9;
     std::vector<uint32_t> argb;
@@ -78,7 +82,17 @@ struct sr_scene {
     bool   cam_valid = false;
     DBuf d_shadow_cache, d_static_claim, d_static_hits;
     bool shadow_cache_empty = true;      // the device cache must be zeroed before its next use
-    DBuf d_offsets, d_rowmap, d_pixels, d_aa, d_stats, d_io[9];
+    DBuf d_pixels, d_aa, d_stats, d_io[9];
+    // per-frame tables (area-light offsets + row map): pinned host staging and device copies, double-buffered; a slot is
+    // rewritten only after the frame that last used it has finished (event), and not at all when the tables are unchanged
+    struct FrameTables {
+        void* host = nullptr; size_t host_cap = 0;
+        DBuf  dev;
+        hipEvent_t used = nullptr; bool in_flight = false;
+        size_t off_bytes = 0, map_bytes = 0;
+    } tables[2];
+    int tables_cur = 0;
+    bool tables_valid = false;
     // per-band scratch of the pipeline.  Two sets + two internal streams: the two halves of a frame run concurrently, so that
     // the short, latency-bound tail kernels of one half (second shaft round, fallback walks) overlap the other half's work
     static constexpr int kMaxSplit = 4;
@@ -87,6 +101,7 @@ struct sr_scene {
         DBuf rlist[sr::kShaftRounds], rstate[sr::kShaftRounds], rcount[sr::kShaftRounds], rcand[sr::kShaftRounds];
         hipStream_t stream = nullptr;
         hipEvent_t  done = nullptr;
+        bool used_last_frame = false;
         void release() {
             DBuf* b[] = {&hits, &hits2, &bounce_levels, &bounce_nlev, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf};
             for (DBuf* x : b) x->release();
@@ -97,6 +112,7 @@ struct sr_scene {
         }
     } scratch[kMaxSplit];
     hipEvent_t fork = nullptr;
+    hipEvent_t multi_done = nullptr;     // (part of a multi-device scene) this part's strips of the current frame are rendered
     int num_cus = 0;
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
     std::vector<double>  offsets_host;
@@ -182,6 +198,7 @@ int validate_frame(const sr_frame* f) {
     if (f->strip_count < 0 || (f->strip_count > 0 && (f->strip_rows <= 0 || f->strip_index < 0 || f->strip_index >= f->strip_count)))
         return fail(SR_ERR_INVALID_ARG, "bad strip parameters");
     if (f->shadow_samples < 0 || f->shadow_samples > 4096) return fail(SR_ERR_INVALID_ARG, "shadow_samples out of range");
+    if ((long long)f->width * f->sub_pixel_res > (1ll << 24) || (long long)f->height > (1ll << 24)) return fail(SR_ERR_INVALID_ARG, "surface too large");
     if (f->max_bounces < 0 || f->max_bounces > 16 || !(f->reflectivity >= 0.0 && f->reflectivity <= 1.0))
         return fail(SR_ERR_INVALID_ARG, "max_bounces must be 0..16 and reflectivity 0..1");
     return SR_OK;
@@ -189,7 +206,7 @@ int validate_frame(const sr_frame* f) {
 
 void clamp_rows(const sr_frame* f, int& a, int& b) {                  // Renderer.cs:1652-1653
     a = std::min(std::max(0, f->start_row), f->height - 1);
-    b = std::min(std::max(0, f->end_row), f->height - 1);
+    b = std::min(std::max(0, f->end_row), f->height - 1);                 // b < a: the row loop does not run (Renderer.cs:1666)
 }
 
 // everything RaytraceGeometry derives per frame (Renderer.cs:1510-1528, 1717)
@@ -266,12 +283,43 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     int rc = prepare_frame(s, f, fc);
     if (rc) return rc;
     if ((rc = sync_geometry(s, (uint32_t)f->trace_mode))) return rc;
-    SR_HIP(s->d_offsets.reserve(s->offsets_host.size() * sizeof(double)));
-    SR_HIP(hipMemcpyAsync(s->d_offsets.p, s->offsets_host.data(), s->offsets_host.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    SR_HIP(s->d_rowmap.reserve(std::max<size_t>(1, s->rowmap_host.size()) * sizeof(int32_t)));
-    if (!s->rowmap_host.empty())
-        SR_HIP(hipMemcpyAsync(s->d_rowmap.p, s->rowmap_host.data(), s->rowmap_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
     if (fc.num_rows == 0) return SR_OK;
+    // ---- frame tables -> device ----
+    const size_t off_bytes = (s->offsets_host.size() * sizeof(double) + 255) / 256 * 256, map_bytes = s->rowmap_host.size() * sizeof(int32_t);
+    {
+        sr_scene::FrameTables* T = &s->tables[s->tables_cur];
+        const bool same = s->tables_valid && T->off_bytes == off_bytes && T->map_bytes == map_bytes && T->host &&
+                          std::memcmp(T->host, s->offsets_host.data(), s->offsets_host.size() * sizeof(double)) == 0 &&
+                          std::memcmp((const char*)T->host + off_bytes, s->rowmap_host.data(), map_bytes) == 0;
+        if (!same) {
+            s->tables_cur ^= 1;
+            T = &s->tables[s->tables_cur];
+            if (T->in_flight) { SR_HIP(hipEventSynchronize(T->used)); T->in_flight = false; }
+            const size_t need = off_bytes + map_bytes;
+            if (need > T->host_cap) {
+                if (T->host) SR_HIP(hipHostFree(T->host));
+                T->host = nullptr; T->host_cap = 0;
+                SR_HIP(hipHostMalloc(&T->host, need + 4096, hipHostMallocDefault));
+                T->host_cap = need + 4096;
+            }
+            SR_HIP(T->dev.reserve(need));
+            std::memcpy(T->host, s->offsets_host.data(), s->offsets_host.size() * sizeof(double));
+            std::memcpy((char*)T->host + off_bytes, s->rowmap_host.data(), map_bytes);
+            T->off_bytes = off_bytes; T->map_bytes = map_bytes;
+            SR_HIP(hipMemcpyAsync(T->dev.p, T->host, need, hipMemcpyHostToDevice, stream));
+            s->tables_valid = true;
+        }
+    }
+    sr_scene::FrameTables& FT = s->tables[s->tables_cur];
+    const double* d_offsets = (const double*)FT.dev.p;
+    const int32_t* d_rowmap = (const int32_t*)((const char*)FT.dev.p + off_bytes);
+    struct MarkUsed {                                               // the slot is busy until everything enqueued below has run
+        sr_scene::FrameTables& t; hipStream_t st;
+        ~MarkUsed() {
+            if (!t.used && hipEventCreateWithFlags(&t.used, hipEventDisableTiming) != hipSuccess) return;
+            if (hipEventRecord(t.used, st) == hipSuccess) t.in_flight = true;
+        }
+    } mark_used{FT, stream};
     const bool static_shadows = (f->flags & SR_F_STATIC_SHADOWS) && (f->flags & SR_F_SHADOWS);
     if (static_shadows) {
         if ((f->flags & SR_F_SINGLE_KERNEL) || f->max_bounces > 0 || f->strip_count > 1)
@@ -293,8 +341,8 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         L.sc = dev_scene(s);
         L.fc = fc;
         L.mode = f->trace_mode;
-        L.offsets = (const double*)s->d_offsets.p;
-        L.row_map = (const int32_t*)s->d_rowmap.p;
+        L.offsets = d_offsets;
+        L.row_map = d_rowmap;
         L.pixels = d_pixels;
         L.stats = d_stats;
         L.stream = stream;
@@ -346,6 +394,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     long long band_rows = std::max<long long>(16, (budget / (wpad * n2)) / 16 * 16);
     band_rows = std::min<long long>(band_rows, ((long long)rows_half + 15) / 16 * 16);
     const long long band_samples = band_rows * wpad * n2;
+    if (shaft && band_samples >= (1ll << 25)) return fail(SR_ERR_UNSUPPORTED, "row band too large for the 25-bit fallback entry ids (surface too wide for this sub-pixel resolution)");
     if (static_shadows) {
         if (band_rows < fc.num_rows) return fail(SR_ERR_UNSUPPORTED, "static shadows: the frame does not fit one row band");
         SR_HIP(s->d_static_hits.reserve((size_t)std::min<long long>(band_samples, (long long)sr::pipeline_static_cells()) * sr::pipeline_hit_record_bytes()));
@@ -367,8 +416,10 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         if (!s->fork) SR_HIP(hipEventCreateWithFlags(&s->fork, hipEventDisableTiming));
         SR_HIP(hipEventRecord(s->fork, stream));                    // the halves start after the caller's earlier work
     }
+    for (auto& sc : s->scratch) sc.used_last_frame = false;
     for (int h = 0; h < halves; ++h) {
         sr_scene::BandScratch& B = s->scratch[h];
+        B.used_last_frame = true;
         if (shadows || bounce_pipe) SR_HIP(B.hits.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
         if (bounce_pipe) {
             // level colours are indexed like the sample buffer: the frame (or compact strip buffer) for one sample per pixel, band-local otherwise
@@ -402,8 +453,8 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.sc = dev_scene(s);
         P.fc = fc;
         P.mode = f->trace_mode;
-        P.offsets = (const double*)s->d_offsets.p;
-        P.row_map = (const int32_t*)s->d_rowmap.p;
+        P.offsets = d_offsets;
+        P.row_map = d_rowmap;
         P.pixels = d_pixels;
         P.samples = (uint32_t*)B.samples.p;
         P.hits = B.hits.p;
@@ -452,6 +503,72 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     return SR_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// One scene over several devices of this process (sr_create_multi).  Rows are independent (the reference itself fans out row
+// blocks, Renderer.cs:1659-1670): part g renders the 16-row strips s with s % n == g of the frame's row range into its own
+// compact device buffer (sr_frame.strip_*), concurrently with the others (every part has its own device, streams and
+// scratch; the calls below only ENQUEUE), and the strips travel straight to where the caller wants them: sr_render copies
+// every part's strips device -> host into the caller's surface (each over its own PCIe link), sr_render_device copies them
+// peer-to-peer (xGMI) into the caller's device surface.  No reduction, no RNG: the frame does not depend on the split.
+// ------------------------------------------------------------------------------------------------------------------
+const int kMultiStripRows = 16;
+
+struct StripRun { int64_t compact_row, image_row, rows; };          // rows [image_row, image_row + rows) sit at compact_row of the part's buffer
+
+// the runs of part g for the clamped row range [a, b]
+std::vector<StripRun> strip_runs(int a, int b, int n, int g) {
+    std::vector<StripRun> runs;
+    int64_t compact = 0;
+    for (int s0 = a / kMultiStripRows; s0 * kMultiStripRows <= b; ++s0) {
+        if (s0 % n != g) continue;
+        const int r0 = std::max(a, s0 * kMultiStripRows), r1 = std::min(b, s0 * kMultiStripRows + kMultiStripRows - 1);
+        if (r1 < r0) continue;
+        runs.push_back({compact, r0, r1 - r0 + 1});
+        compact += r1 - r0 + 1;
+    }
+    return runs;
+}
+
+// copy the runs of one part to the full surface `dst` (host or device memory): the full strips between the (possibly
+// partial) first and last one form an arithmetic progression -> ONE strided 2-D copy; the edges are copied on their own
+hipError_t copy_runs(const std::vector<StripRun>& runs, int n, int width, const uint32_t* src, uint32_t* dst, hipMemcpyKind kind, hipStream_t st) {
+    const size_t row_bytes = (size_t)width * 4;
+    size_t i = 0;
+    while (i < runs.size()) {
+        size_t j = i;
+        while (j + 1 < runs.size() && runs[j].rows == kMultiStripRows && runs[j + 1].rows == kMultiStripRows &&
+               runs[j + 1].image_row - runs[j].image_row == (int64_t)n * kMultiStripRows) ++j;
+        if (j > i) {
+            const size_t strip_bytes = row_bytes * kMultiStripRows;
+            hipError_t e = hipMemcpy2DAsync(dst + runs[i].image_row * width, strip_bytes * n, src + runs[i].compact_row * width, strip_bytes,
+                                            strip_bytes, j - i + 1, kind, st);
+            if (e != hipSuccess) return e;
+            i = j + 1;
+        } else {
+            hipError_t e = hipMemcpyAsync(dst + runs[i].image_row * width, src + runs[i].compact_row * width, row_bytes * runs[i].rows, kind, st);
+            if (e != hipSuccess) return e;
+            ++i;
+        }
+    }
+    return hipSuccess;
+}
+
+// frames that cannot be split (one global fill order) are rendered whole by the first part
+bool multi_splittable(const sr_frame* f) { return !((f->flags & SR_F_STATIC_SHADOWS) && (f->flags & SR_F_SHADOWS)) && f->strip_count <= 0; }
+
+void clone_host_model(sr_scene* d, const sr_scene* src) {
+    d->v9 = src->v9; d->argb = src->argb;
+    for (int a = 0; a < 3; ++a) { d->bmin[a] = src->bmin[a]; d->bmax[a] = src->bmax[a]; }
+    d->have_model = src->have_model;
+    d->tri_recs = src->tri_recs;
+    d->root = src->root;
+    d->shadow_cache_empty = true;
+    d->ref = sr::RefTree(); d->bvh = sr::Bvh(); d->bvh_on_device = false;
+    d->tris_dirty = d->ref_dirty = d->bvh_dirty = true;
+    d->cam_valid = false;
+}
+
 }  // namespace
 
 extern "C" {
@@ -477,14 +594,48 @@ int sr_create(int32_t device, sr_scene** out) {
     return SR_OK;
 }
 
+int sr_create_multi(const int32_t* devices, int32_t n, sr_scene** out) {
+    if (!out) return fail(SR_ERR_INVALID_ARG, "out is NULL");
+    *out = nullptr;
+    if (!devices || n < 1 || n > 64) return fail(SR_ERR_INVALID_ARG, "sr_create_multi needs 1..64 device ordinals");
+    sr_scene* m = new sr_scene();
+    m->device = -2;
+    for (int i = 0; i < n; ++i) {
+        sr_scene* part = nullptr;
+        int rc = devices[i] >= 0 ? sr_create(devices[i], &part) : fail(SR_ERR_INVALID_ARG, "device ordinals must be >= 0");
+        if (rc) { for (sr_scene* q : m->parts) sr_destroy(q); delete m; return rc; }
+        m->parts.push_back(part);
+    }
+    // strips are gathered peer-to-peer into the first part's device (sr_render_device); a refusal only means staged copies
+    for (int i = 1; i < n; ++i) {
+        if (devices[i] == devices[0]) continue;
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can && hipSetDevice(devices[0]) == hipSuccess)
+            (void)hipDeviceEnablePeerAccess(devices[i], 0);
+        (void)hipGetLastError();
+    }
+    *out = m;
+    return SR_OK;
+}
+
+int32_t sr_device_count(const sr_scene* s) { return !s ? 0 : (s->parts.empty() ? (s->device >= 0 ? 1 : 0) : (int32_t)s->parts.size()); }
+
 void sr_destroy(sr_scene* s) {
     if (!s) return;
+    if (!s->parts.empty()) {
+        if (s->multi_done && use_device(s->parts[0]) == SR_OK) (void)hipEventDestroy(s->multi_done);
+        for (sr_scene* q : s->parts) sr_destroy(q);
+        delete s;
+        return;
+    }
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
-                        &s->d_v9, &s->d_bcam, &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_offsets, &s->d_rowmap, &s->d_pixels, &s->d_aa, &s->d_stats};
+                        &s->d_v9, &s->d_bcam, &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_pixels, &s->d_aa, &s->d_stats};
         for (DBuf* b : bufs) b->release();
         for (auto& sc : s->scratch) sc.release();
+        for (auto& t : s->tables) { t.dev.release(); if (t.host) (void)hipHostFree(t.host); if (t.used) (void)hipEventDestroy(t.used); }
         if (s->fork) (void)hipEventDestroy(s->fork);
+        if (s->multi_done) (void)hipEventDestroy(s->multi_done);
         for (DBuf& b : s->d_io) b.release();
         for (int k = 0; k < sr::K_COUNT; ++k)
             for (hipEvent_t e : s->ev[k]) (void)hipEventDestroy(e);
@@ -493,6 +644,11 @@ void sr_destroy(sr_scene* s) {
 }
 
 int sr_set_triangles(sr_scene* s, const double* v9, const uint32_t* argb, int64_t n, const double box_min[3], const double box_max[3]) {
+    if (s && !s->parts.empty()) {                                  // host work once, the records are replicated
+        int rc = sr_set_triangles(s->parts[0], v9, argb, n, box_min, box_max);
+        for (size_t i = 1; i < s->parts.size() && !rc; ++i) clone_host_model(s->parts[i], s->parts[0]);
+        return rc;
+    }
     if (!s || n < 0 || (n > 0 && (!v9 || !argb)) || !box_min || !box_max) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_set_triangles");
     if (n > 0x7fffff00) return fail(SR_ERR_INVALID_ARG, "too many triangles");
     s->shadow_cache_empty = true;                         // new model: what a new ShadowMethod starts with
@@ -514,6 +670,10 @@ int sr_set_triangles(sr_scene* s, const double* v9, const uint32_t* argb, int64_
 }
 
 int sr_set_extra_geometry(sr_scene* s, const sr_prim* prims, int32_t n) {
+    if (s && !s->parts.empty()) {
+        for (sr_scene* q : s->parts) { int rc = sr_set_extra_geometry(q, prims, n); if (rc) return rc; }
+        return SR_OK;
+    }
     if (!s || n < 0 || (n > 0 && !prims)) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_set_extra_geometry");
     std::vector<sr::Rec128> recs;
     for (int i = 0; i < n; ++i) {
@@ -524,6 +684,14 @@ int sr_set_extra_geometry(sr_scene* s, const sr_prim* prims, int32_t n) {
                 recs.push_back(sr::make_sphere_record({q.p[0], q.p[1], q.p[2]}, q.p[3], q.argb));
                 break;
             case 1: recs.push_back(sr::make_plane_record({q.p[0], q.p[1], q.p[2]}, {q.p[3], q.p[4], q.p[5]}, q.argb)); break;
+            case 3: {                                              // an existing Plane object: its stored unit normal and originDist, verbatim
+                sr::Rec128 r;
+                std::memset(&r, 0, sizeof(r));
+                r.p[0] = q.p[0]; r.p[1] = q.p[1]; r.p[2] = q.p[2]; r.p[3] = q.p[3];
+                r.color = q.argb; r.aux = 1;
+                recs.push_back(r);
+                break;
+            }
             case 2: {
                 sr::Rec128 r = sr::make_triangle_record({q.p[0], q.p[1], q.p[2]}, {q.p[3], q.p[4], q.p[5]}, {q.p[6], q.p[7], q.p[8]}, q.argb, 2);
                 recs.push_back(r);
@@ -538,8 +706,31 @@ int sr_set_extra_geometry(sr_scene* s, const sr_prim* prims, int32_t n) {
 }
 
 int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_leaf) {
+    if (s && !s->parts.empty()) {
+        // the host structures (reference tree, SAH BVH) are built once and copied; a device-built BVH is built by every part
+        int rc = sr_build(s->parts[0], modes, max_depth, max_per_leaf);
+        for (size_t i = 1; i < s->parts.size() && !rc; ++i) {
+            sr_scene* q = s->parts[i];
+            if ((modes & SR_BUILD_ON_DEVICE) && (modes & (1u << SR_MODE_BVH))) {
+                q->ref = s->parts[0]->ref; q->ref_dirty = true;
+                rc = sr_build(q, modes & ~(1u << SR_MODE_REF_TREE), max_depth, max_per_leaf);
+                if (!rc && (modes & (1u << SR_MODE_REF_TREE)) && (rc = use_device(q)) == SR_OK) rc = sync_geometry(q, SR_MODE_REF_TREE);
+                continue;
+            }
+            if (modes & (1u << SR_MODE_REF_TREE)) { q->ref = s->parts[0]->ref; q->ref_dirty = true; }
+            if (modes & (1u << SR_MODE_BVH)) { q->bvh = s->parts[0]->bvh; q->bvh_on_device = false; q->bvh_dirty = true; }
+            if ((rc = use_device(q))) break;
+            if (modes & (1u << SR_MODE_REF_TREE)) if ((rc = sync_geometry(q, SR_MODE_REF_TREE))) break;
+            if (modes & (1u << SR_MODE_BVH)) if ((rc = sync_geometry(q, SR_MODE_BVH))) break;
+            rc = sync_geometry(q, SR_MODE_BRUTE);
+        }
+        return rc;
+    }
     if (!s) return fail(SR_ERR_INVALID_ARG, "scene is NULL");
     if (!s->have_model) return fail(SR_ERR_NO_MODEL, "sr_build before sr_set_triangles");
+    // leaves are packed as (first record | count << 28) and traversal stack words as (node | bound << bits): 2^28 records / 2^26 nodes
+    if ((modes & (1u << SR_MODE_BVH)) && s->argb.size() >= (1u << 26))
+        return fail(SR_ERR_UNSUPPORTED, "the library's BVH holds at most 2^26 - 1 triangles");
     if (modes & (1u << SR_MODE_REF_TREE)) {
         int md = max_depth > 0 ? max_depth : 15, mg = max_per_leaf > 0 ? max_per_leaf : 25;   // SpatialSubdivision.cs:269-270
         if (!sr::build_ref_tree(s->v9, s->bmin, s->bmax, md, mg, s->ref))
@@ -597,6 +788,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
 }
 
 int sr_tree_stats(const sr_scene* s, int32_t out[4]) {
+    if (s && !s->parts.empty()) s = s->parts[0];
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
     if (!s->ref.built) return fail(SR_ERR_NOT_BUILT, "reference tree not built");
     out[0] = s->ref.tree_depth; out[1] = s->ref.num_nodes; out[2] = s->ref.num_leaf_nodes; out[3] = s->ref.num_nodes - s->ref.num_leaf_nodes;
@@ -604,6 +796,7 @@ int sr_tree_stats(const sr_scene* s, int32_t out[4]) {
 }
 
 int sr_bvh_stats(const sr_scene* s, int64_t out[4]) {
+    if (s && !s->parts.empty()) s = s->parts[0];
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
     if (!s->bvh.built) return fail(SR_ERR_NOT_BUILT, "BVH not built");
     out[0] = s->bvh.depth; out[1] = (int64_t)(s->bvh_on_device ? s->bvh_num_nodes : s->bvh.nodes.size()); out[2] = (int64_t)s->tri_recs.size(); out[3] = s->bvh_on_device ? 1 : 0;
@@ -612,21 +805,97 @@ int sr_bvh_stats(const sr_scene* s, int64_t out[4]) {
 
 int64_t sr_frame_pixel_count(const sr_frame* f) {
     if (!f || f->width <= 0 || f->height <= 0) return 0;
-    if (f->strip_count <= 0) return (int64_t)f->width * f->height;
     int a, b;
     clamp_rows(f, a, b);
+    if (f->strip_count <= 0) return (int64_t)f->width * f->height;
     int64_t rows = 0;
     for (int r = a; r <= b; ++r) if (row_owned(f, r)) rows++;
     return rows * f->width;
 }
 
 int sr_reset_shadow_cache(sr_scene* s) {
+    if (s && !s->parts.empty()) { for (sr_scene* q : s->parts) q->shadow_cache_empty = true; return SR_OK; }
     if (!s) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_reset_shadow_cache");
     s->shadow_cache_empty = true;
     return SR_OK;
 }
 
+static int multi_render(sr_scene* m, const sr_frame* f, int32_t* host_pixels, void* d_pixels, hipStream_t user_stream, uint64_t* stats4, uint64_t* d_stats) {
+    int rc = validate_frame(f);
+    if (rc) return rc;
+    if (d_stats) return fail(SR_ERR_UNSUPPORTED, "device-side statistics are per device: use sr_render / sr_last_ray_stats with a multi-device scene");
+    const int n = (int)m->parts.size();
+    if (!multi_splittable(f)) {                                     // static shadow cache / caller-made strips: the first part renders it
+        return host_pixels ? sr_render(m->parts[0], f, host_pixels, stats4) : sr_render_device(m->parts[0], f, d_pixels, user_stream, nullptr);
+    }
+    if ((rc = check_mode(m->parts[0], f->trace_mode))) return rc;
+    int a, b;
+    clamp_rows(f, a, b);
+    if (b < a) { if (stats4) std::memset(stats4, 0, 4 * sizeof(uint64_t)); return SR_OK; }
+    // ---- every part enqueues its strips on its own device (nothing below waits for the GPU until all have been enqueued) ----
+    std::vector<sr_frame> fg(n, *f);
+    for (int g = 0; g < n; ++g) {
+        sr_scene* q = m->parts[g];
+        if (m->multi_done) {                                        // the previous frame's gather may still be reading this part's strips
+            if ((rc = use_device(q))) return rc;
+            SR_HIP(hipStreamWaitEvent(nullptr, m->multi_done, 0));
+        }
+        fg[g].strip_rows = kMultiStripRows; fg[g].strip_count = n; fg[g].strip_index = g;
+        const int64_t count = sr_frame_pixel_count(&fg[g]);
+        if (count == 0) continue;
+        if ((rc = check_mode(q, f->trace_mode))) return rc;
+        if ((rc = use_device(q))) return rc;
+        SR_HIP(q->d_pixels.reserve((size_t)count * 4));
+        unsigned long long* ds = nullptr;
+        if (stats4) {
+            SR_HIP(q->d_stats.reserve(16 * sizeof(uint64_t)));
+            SR_HIP(hipMemsetAsync(q->d_stats.p, 0, 16 * sizeof(uint64_t), nullptr));
+            ds = (unsigned long long*)q->d_stats.p;
+        }
+        if ((rc = render_common(q, &fg[g], (uint32_t*)q->d_pixels.p, nullptr, ds))) return rc;
+        if (!q->multi_done) SR_HIP(hipEventCreateWithFlags(&q->multi_done, hipEventDisableTiming));
+        SR_HIP(hipEventRecord(q->multi_done, nullptr));
+    }
+    // ---- the strips go straight to the caller's surface ----
+    for (int g = 0; g < n; ++g) {
+        sr_scene* q = m->parts[g];
+        const std::vector<StripRun> runs = strip_runs(a, b, n, g);
+        if (runs.empty()) continue;
+        if (host_pixels) {
+            if ((rc = use_device(q))) return rc;
+            SR_HIP(copy_runs(runs, n, f->width, (const uint32_t*)q->d_pixels.p, (uint32_t*)host_pixels, hipMemcpyDeviceToHost, nullptr));
+        } else {
+            if ((rc = use_device(m->parts[0]))) return rc;
+            SR_HIP(hipStreamWaitEvent(user_stream, q->multi_done, 0));
+            SR_HIP(copy_runs(runs, n, f->width, (const uint32_t*)q->d_pixels.p, (uint32_t*)d_pixels, hipMemcpyDefault, user_stream));
+        }
+    }
+    if (!host_pixels) {
+        if ((rc = use_device(m->parts[0]))) return rc;
+        if (!m->multi_done) SR_HIP(hipEventCreateWithFlags(&m->multi_done, hipEventDisableTiming));
+        SR_HIP(hipEventRecord(m->multi_done, user_stream));
+    }
+    if (host_pixels) {
+        for (int k = 0; k < 16; ++k) m->last_stats[k] = 0;
+        for (int g = 0; g < n; ++g) {
+            sr_scene* q = m->parts[g];
+            if ((rc = use_device(q))) return rc;
+            SR_HIP(hipStreamSynchronize(nullptr));
+            if (stats4 && sr_frame_pixel_count(&fg[g]) > 0) {
+                SR_HIP(hipMemcpy(q->last_stats, q->d_stats.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                for (int k = 0; k < 16; ++k) m->last_stats[k] += q->last_stats[k];
+            }
+        }
+        if (stats4) std::memcpy(stats4, m->last_stats, 4 * sizeof(uint64_t));
+    }
+    return SR_OK;
+}
+
 int sr_render_device(sr_scene* s, const sr_frame* f, void* d_pixels, void* hip_stream, uint64_t* d_stats) {
+    if (s && !s->parts.empty()) {
+        if (!d_pixels) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_render_device");
+        return multi_render(s, f, nullptr, d_pixels, (hipStream_t)hip_stream, nullptr, d_stats);
+    }
     if (!s || !d_pixels) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_render_device");
     int rc = validate_frame(f);
     if (rc) return rc;
@@ -638,12 +907,21 @@ int sr_render_device(sr_scene* s, const sr_frame* f, void* d_pixels, void* hip_s
 }
 
 int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]) {
+    if (s && !s->parts.empty()) {
+        if (!pixels) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_render");
+        return multi_render(s, f, pixels, nullptr, nullptr, stats, nullptr);
+    }
     if (!s || !pixels) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_render");
     int rc = validate_frame(f);
     if (rc) return rc;
     if ((rc = check_mode(s, f->trace_mode))) return rc;
     if ((rc = use_device(s))) return rc;
     int64_t count = sr_frame_pixel_count(f);
+    {
+        int a, b;
+        clamp_rows(f, a, b);
+        if (b < a || count == 0) { if (stats) std::memset(stats, 0, 4 * sizeof(uint64_t)); return SR_OK; }   // rayTraceStartRow > EndRow: nothing is drawn
+    }
     SR_HIP(s->d_pixels.reserve((size_t)count * 4));
     unsigned long long* d_stats = nullptr;
     if (stats) {
@@ -672,6 +950,7 @@ int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]
 
 int sr_trace_rays(sr_scene* s, int32_t target, int64_t n, const double* starts, const double* dirs, uint8_t* hit, double* ray_frac,
                   double* pos, double* normal, uint32_t* color, int32_t* tri_index, int32_t* counters) {
+    if (s && !s->parts.empty()) s = s->parts[0];
     if (!s || n < 0 || (n > 0 && (!starts || !dirs))) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_trace_rays");
     bool with_extra = (target & SR_TARGET_ROOT) != 0;
     int mode = target & 0xff;
@@ -716,8 +995,9 @@ int sr_load_3ds(sr_scene* s, const uint8_t* data, size_t len) {
     if (!err.empty()) return fail(SR_ERR_FORMAT, err);
     return sr_set_triangles(s, m.v9.data(), m.argb.data(), (int64_t)m.argb.size(), m.bmin, m.bmax);
 }
-int64_t sr_num_triangles(const sr_scene* s) { return s ? (int64_t)s->argb.size() : 0; }
+int64_t sr_num_triangles(const sr_scene* s) { if (s && !s->parts.empty()) s = s->parts[0]; return s ? (int64_t)s->argb.size() : 0; }
 int sr_get_triangles(const sr_scene* s, double* v9, uint32_t* argb, double box_min[3], double box_max[3]) {
+    if (s && !s->parts.empty()) s = s->parts[0];
     if (!s || !s->have_model) return fail(SR_ERR_NO_MODEL, "no model");
     if (v9) std::memcpy(v9, s->v9.data(), s->v9.size() * sizeof(double));
     if (argb) std::memcpy(argb, s->argb.data(), s->argb.size() * sizeof(uint32_t));
@@ -746,6 +1026,7 @@ void sr_make_random_triangles(int32_t seed, int64_t n, double space, double exte
 
 // ---- surface passes, Renderer.cs:765-767 ----
 int sr_post_process_device(sr_scene* s, void* d_pixels, int64_t count, int32_t style, uint32_t background_color, void* hip_stream) {
+    if (s && !s->parts.empty()) s = s->parts[0];               // surface passes / timings: the first device
     if (!s || count < 0 || (count > 0 && !d_pixels)) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_post_process");
     if (style < SR_STYLE_STANDARD || style > SR_STYLE_DEPTH_BANDED)
         return fail(SR_ERR_UNSUPPORTED, "render style " + std::to_string(style) + " is not a per-pixel colour function (Style.Normals needs the rasteriser's depth buffer)");
@@ -762,6 +1043,7 @@ int sr_post_process_device(sr_scene* s, void* d_pixels, int64_t count, int32_t s
 }
 
 int sr_post_process(sr_scene* s, int32_t* pixels, int64_t count, int32_t style, uint32_t background_color) {
+    if (s && !s->parts.empty()) s = s->parts[0];               // surface passes / timings: the first device
     if (!s || count < 0 || (count > 0 && !pixels)) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_post_process");
     if (style < SR_STYLE_STANDARD || style > SR_STYLE_DEPTH_BANDED)
         return fail(SR_ERR_UNSUPPORTED, "render style " + std::to_string(style) + " is not a per-pixel colour function (Style.Normals needs the rasteriser's depth buffer)");
@@ -776,6 +1058,7 @@ int sr_post_process(sr_scene* s, int32_t* pixels, int64_t count, int32_t style, 
 }
 
 int sr_anti_alias_device(sr_scene* s, const void* d_src, int32_t dst_width, int32_t dst_height, int32_t resolution, void* d_dst, void* hip_stream) {
+    if (s && !s->parts.empty()) s = s->parts[0];               // surface passes / timings: the first device
     if (!s || !d_src || !d_dst || dst_width <= 0 || dst_height <= 0) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_anti_alias");
     if (resolution < 1 || resolution > 64 || (int64_t)dst_width * resolution > INT_MAX || (int64_t)dst_height * resolution > INT_MAX)
         return fail(SR_ERR_INVALID_ARG, "AntiAliasResolution must be in 1..64");           // Renderer.cs:374 (> 0)
@@ -791,6 +1074,7 @@ int sr_anti_alias_device(sr_scene* s, const void* d_src, int32_t dst_width, int3
 }
 
 int sr_anti_alias(sr_scene* s, const int32_t* src, int32_t dst_width, int32_t dst_height, int32_t resolution, int32_t* dst) {
+    if (s && !s->parts.empty()) s = s->parts[0];               // surface passes / timings: the first device
     if (!s || !src || !dst || dst_width <= 0 || dst_height <= 0) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_anti_alias");
     if (resolution < 1 || resolution > 64 || (int64_t)dst_width * resolution > INT_MAX || (int64_t)dst_height * resolution > INT_MAX)
         return fail(SR_ERR_INVALID_ARG, "AntiAliasResolution must be in 1..64");
@@ -807,18 +1091,29 @@ int sr_anti_alias(sr_scene* s, const int32_t* src, int32_t dst_width, int32_t ds
 }
 
 int sr_debug_counters(sr_scene* s, uint32_t out[8]) {
+    if (s && !s->parts.empty() && out) {
+        for (int i = 0; i < 8; ++i) out[i] = 0;
+        for (sr_scene* q : s->parts) { uint32_t c[8]; int rc = sr_debug_counters(q, c); if (rc) return rc; for (int i = 0; i < 8; ++i) out[i] += c[i]; }
+        return SR_OK;
+    }
     /* diagnostics: the pipeline's device counters after the last band of the last frame:
        hit_count, k_shadow work head, fallback_count, fallback work head */
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
     int rc = use_device(s);
     if (rc) return rc;
-    if (!s->scratch[0].counters.p) { for (int i = 0; i < 8; ++i) out[i] = 0; return SR_OK; }
+    for (int i = 0; i < 8; ++i) out[i] = 0;
     SR_HIP(hipDeviceSynchronize());
-    SR_HIP(hipMemcpy(out, s->scratch[0].counters.p, 32, hipMemcpyDeviceToHost));   // first half of the frame
+    for (auto& sc : s->scratch) {                                   // every part-frame pipeline of the last frame (last band of each)
+        if (!sc.counters.p || !sc.used_last_frame) continue;
+        uint32_t c[8];
+        SR_HIP(hipMemcpy(c, sc.counters.p, 32, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 8; ++i) out[i] += c[i];
+    }
     return SR_OK;
 }
 
 int sr_debug_set(sr_scene* s, int32_t key, int64_t value) {
+    if (s && !s->parts.empty()) { for (sr_scene* q : s->parts) { int rc = sr_debug_set(q, key, value); if (rc) return rc; } return SR_OK; }
     if (!s || key < 0 || key >= SR_DBG_COUNT) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_debug_set");
     s->dbg[key] = value;
     return SR_OK;
@@ -826,10 +1121,12 @@ int sr_debug_set(sr_scene* s, int32_t key, int64_t value) {
 
 void sr_reset_kernel_times(sr_scene* s) {
     if (!s) return;
+    if (!s->parts.empty()) { for (sr_scene* q : s->parts) sr_reset_kernel_times(q); return; }
     for (int k = 0; k < sr::K_COUNT; ++k) s->ev_used[k] = 0;
 }
 
 int sr_kernel_times(sr_scene* s, sr_kernel_time* out, int32_t cap) {
+    if (s && !s->parts.empty()) s = s->parts[0];               // surface passes / timings: the first device
     if (!s || !out || cap <= 0) return 0;
     if (use_device(s)) return 0;
     int n = 0;

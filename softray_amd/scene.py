@@ -24,11 +24,21 @@ def _check(rc):
 
 
 class GpuScene:
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """device: one HIP ordinal (-1 = host-only scene); devices: a list of ordinals -> ONE scene over several GPUs of this
+        process (sr_create_multi: frames are split into interleaved 16-row strips inside the library)."""
         h = C.c_void_p()
-        _check(_lib.lib().sr_create(int(device), C.byref(h)))
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            _check(_lib.lib().sr_create_multi(arr, len(devices), C.byref(h)))
+            device = int(devices[0]) if len(devices) else -1
+        else:
+            _check(_lib.lib().sr_create(int(device), C.byref(h)))
         self._h = h
         self.device = device
+
+    def device_count(self):
+        return int(_lib.lib().sr_device_count(self._h))
 
     def close(self):
         if getattr(self, "_h", None):
@@ -94,6 +104,10 @@ class GpuScene:
 
     def render(self, frame, out=None, stats=True):
         n = self.pixel_count(frame)
+        if out is not None:
+            if not (isinstance(out, np.ndarray) and out.dtype.itemsize == 4 and out.dtype.kind in "iu" and out.flags["C_CONTIGUOUS"]
+                    and out.flags["WRITEABLE"] and out.size >= n):
+                raise ValueError("out must be a writable C-contiguous int32/uint32 array of at least %d pixels" % n)
         pixels = out if out is not None else np.zeros(n, dtype=np.int32)
         st = np.zeros(4, dtype=np.uint64) if stats else None
         _check(_lib.lib().sr_render(self._h, C.byref(frame), _p(pixels), _p(st)))

@@ -27,7 +27,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(L, n), "libsoftray_hip.so does not export %s" % n
     assert sorted(sa._lib.SYMBOLS) == names
-    assert L.sr_abi_version() == 2              # sr_frame gained `concurrency` (static shadows)
+    assert L.sr_abi_version() == 3              # sr_debug_set / sr_bvh_stats, 16 ray statistics
 
 
 def test_frame_layout_matches_oracle_frame():
@@ -35,6 +35,35 @@ def test_frame_layout_matches_oracle_frame():
     for (n1, t1), (n2, t2) in zip(sa.Frame._fields_, orc.Frame._fields_):
         assert n1 == n2 and C.sizeof(t1) == C.sizeof(t2)
         assert getattr(sa.Frame, n1).offset == getattr(orc.Frame, n2).offset
+
+
+def test_layout_contract_of_header_ctypes_and_csharp():
+    """sr_frame / sr_prim offsets: the header's static asserts (compiled into the library), the ctypes mirror and the offsets
+    written next to the C# struct fields must agree."""
+    header = open(HEADER).read()
+    assert "sizeof(sr_frame) == %d" % C.sizeof(sa.Frame) in header and "sizeof(sr_prim) == %d" % C.sizeof(sa._lib.Prim) in header
+    cs = open(os.path.join(ROOT, "bindings", "csharp", "GpuRenderer.cs")).read()
+    for name, _ in sa.Frame._fields_:
+        off = getattr(sa.Frame, name).offset
+        m = re.search(r"/\*\s*@%d\s*\*/[^;]*\b%s\b" % (off, name), cs)
+        assert m, "GpuRenderer.cs: field %s is not annotated with offset @%d" % (name, off)
+        hm = re.search(r"offsetof\(sr_frame, %s\) == (\d+)" % name, header)
+        if hm:
+            assert int(hm.group(1)) == off
+
+
+def test_library_never_reads_the_environment():
+    """A drop-in must not change its schedule with the host's environment: every hook goes through sr_debug_set."""
+    pkg = os.path.join(ROOT, "softray_amd", "csrc")
+    for f in os.listdir(pkg):
+        if not os.path.isfile(os.path.join(pkg, f)) or f.endswith((".so", ".o")):
+            continue
+        text = open(os.path.join(pkg, f), errors="ignore").read()
+        assert "getenv" not in text, "%s reads the environment" % f
+    s = sa.GpuScene(device=-1)
+    s.debug_set(sa._lib.DBG_ROUND_CAP0, 5)
+    with pytest.raises(sa.SoftrayError):
+        s.debug_set(99, 1)
 
 
 def test_no_cpu_fallback():

@@ -471,6 +471,49 @@ def test_packet_primary_walk_against_private_walks():
     assert int(np.count_nonzero((got.reshape(100, 100) & 0xFFFFFF) != golden_rgb("shading", 100))) == 0
 
 
+def test_multi_device_scene_in_library():
+    """sr_create_multi: one scene over several devices of one process (here the same GPU several times -- the code path, the
+    strip bookkeeping and the strided gathers are those of a real node): host surface and device surface, odd row ranges,
+    shadows, sub-pixel sampling, statistics, extra geometry, static shadows (rendered whole by the first device)."""
+    import torch
+    v9, argb, bmin, bmax = unit_cube_scene(20000)
+    single = sa.GpuScene(0)
+    single.set_triangles(v9, argb, bmin, bmax)
+    single.build((sa.MODE_BVH, sa.MODE_REF_TREE))
+    for ndev in (2, 3, 8):
+        multi = sa.GpuScene(devices=[0] * ndev)
+        assert multi.device_count() == ndev
+        multi.set_triangles(v9, argb, bmin, bmax)
+        multi.build((sa.MODE_BVH, sa.MODE_REF_TREE))
+        for kw, mode in ((dict(shadows=True), sa.MODE_BVH), (dict(sub_pixel_res=2), sa.MODE_BVH), (dict(start_row=5, end_row=190), sa.MODE_REF_TREE),
+                         (dict(start_row=37, end_row=41), sa.MODE_BVH), (dict(shadows=True, static_shadows=True), sa.MODE_BVH)):
+            f = as_sr(make_frame(150, 203, depth=1.5, **kw), mode)
+            single.reset_shadow_cache(); multi.reset_shadow_cache()
+            canvas_a = np.full(150 * 203, 0x12345678, dtype=np.int32); canvas_b = canvas_a.copy()
+            a, sta = single.render(f, out=canvas_a)
+            b, stb = multi.render(f, out=canvas_b)
+            assert np.array_equal(a, b), (ndev, kw)
+            if mode == sa.MODE_REF_TREE:
+                assert np.array_equal(sta, stb)                          # the reference's counters do not depend on the split
+            assert sta[0] == stb[0]
+        # device surface on devices[0], enqueued on a torch stream, twice in a row without a host sync in between
+        f = as_sr(make_frame(150, 203, depth=1.5, shadows=True), sa.MODE_BVH)
+        want, _ = single.render(f)
+        dev = torch.device("cuda", 0)
+        out = torch.zeros(150 * 203, dtype=torch.int32, device=dev)
+        st = torch.cuda.current_stream(dev)
+        multi.render_device(f, out.data_ptr(), st.cuda_stream)
+        multi.render_device(f, out.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want)
+        prims = c1_spheres(4)
+        multi.set_extra(prims); single.set_extra(prims)
+        f = as_sr(make_frame(96, 64, depth=1.5, shadows=True), sa.MODE_BVH)
+        assert np.array_equal(multi.render(f)[0], single.render(f)[0])
+        single.set_extra([])
+        multi.close()
+
+
 def test_full_size_properties():
     """BASELINE-size checks (1 M triangles, up to 4096^2) through size-independent properties: the three shadow schedules
     agree, the union of interleaved strips is the frame, rendering is idempotent, the own BVH and the literal reference
