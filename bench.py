@@ -4,20 +4,26 @@
 Metric (BASELINE.json): Mrays/s = PRIMARY rays per second = W*H*subPixelRes^2 / t_frame, on the
 1M-random-triangle scene (System.Random seed 12345) at 4096x4096, shading + the
 reference's 100-sample dynamic soft shadows ("primary+shadow"), traced through the library's BVH.
-A "step" is one full frame.  The scene, the BVH and the frame constants are resident in HBM before
-the timed region; the frame stays in HBM (the PCIe-inclusive rate is reported separately).
+A "step" is one full frame INCLUDING its way back to the host (SURVEY 8d / BASELINE.md 3: "pixel
+read-back / RCCL gather included"): the scene, the BVH and the frame constants are resident in HBM
+before the timed region; every step renders into one of two device surfaces and copies it into one
+of two pinned host surfaces on a copy stream, so the read-back of frame k overlaps the rendering of
+frame k + 1; the timed region ends when the last frame has arrived on the host.  The rate with the
+frame left in HBM is reported beside it (`hbm_resident`).
 
     python bench.py --gpus N --steps K --warmup W
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is row-tiled in interleaved
 16-row strips, every rank renders its strips into a compact device buffer and ONE RCCL gather over
-xGMI collects the strips on rank 0 ("scaling": "strong" -- the frame is fixed).
+xGMI collects the strips on rank 0 ("scaling": "strong" -- the frame is fixed), which reads it back.
+`--in-library` (single process): the same split behind the C ABI (sr_create_multi).
 """
 import argparse
-import ctypes
+import copy
 import json
 import math
 import os
+import shutil
 import sys
 import time
 
@@ -33,7 +39,9 @@ from softray_amd import renderer as R
 from softray_amd.distributed import StripGather
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-S_NODE, S_TRI, S_PIX = 64, 128, 4   # bytes: BVH node (two fp32 child boxes + links), triangle record, pixel store
+VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9     # CUs x SIMDs x lanes per cycle x clock: 39.3 T lane-instructions / s (an FMA counts once)
+S_NODE, S_TRI, S_SLAB, S_PIX = 64, 128, 64, 4  # bytes: BVH node, FP64 triangle record, fp32 TriSlab / CamCone record, pixel store
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02_final")
 
 
 def make_frame(args, strips=None):
@@ -80,11 +88,7 @@ def make_frame(args, strips=None):
     return f
 
 
-def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=20.0):
-    """The reference's CPU path = the C++ oracle (statement-level restatement; real C# cannot be built here),
-    reference tree depth 15 / 25 per leaf, row-block threads on all host cores, timed on a centred band of
-    rows of the SAME frame (bounded sample)."""
-    from oracle import oracle_py as orc                              # the only place bench.py touches oracle/
+def host_cores():
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:                                                            # honour a cgroup CPU quota (the GPU box gives each job a share)
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -92,6 +96,16 @@ def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=20.0):
             cores = max(1, min(cores, int(math.ceil(int(q) / int(per)))))
     except Exception:
         pass
+    return cores
+
+
+def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=22.0):
+    """The reference's CPU path = the C++ oracle (statement-level restatement; real C# cannot be built here), reference tree
+    depth 15 / 25 per leaf, row-block threads like Renderer.cs:1659-1670, timed on a centred band of rows of the SAME frame
+    (bounded sample) at threads = all host cores (the headline `value`) and threads = 4 (rayTraceConcurrency's default,
+    Renderer.cs:82), as SURVEY 8d / BASELINE.md 3 ask."""
+    from oracle import oracle_py as orc                              # the only place bench.py touches oracle/
+    cores = host_cores()
     o = orc.Scene()
     o.set_triangles(v9, argb, bmin, bmax)
     t0 = time.time()
@@ -100,29 +114,82 @@ def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=20.0):
     f = orc.Frame.from_buffer_copy(bytes(make_frame(args)))
     f.trace_mode = orc.MODE_REF_TREE
     mid = args.res // 2
-    rows, total_rows, total_s = 1, 0, 0.0
     scratch = np.zeros(args.res * args.res, dtype=np.int32)
-    while True:                                                      # grow the band until ~budget_s of CPU work
-        f.start_row, f.end_row = mid - rows // 2, mid - rows // 2 + rows - 1
-        t0 = time.time()
-        o.render(f, threads=cores, out=scratch)
-        dt = time.time() - t0
-        total_rows, total_s = rows, dt
-        if dt >= budget_s * 0.5 or rows >= args.res:
-            break
-        rows = min(args.res, max(rows * 2, int(rows * budget_s / max(dt, 1e-3) * 0.8)))
-    rays = total_rows * args.res * args.spp * args.spp
-    return {"value": rays / total_s / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+
+    def timed(threads, budget):
+        rows, total_rows, total_s = 1, 0, 0.0
+        while True:                                                  # grow the band until ~budget of CPU work
+            f.start_row, f.end_row = mid - rows // 2, mid - rows // 2 + rows - 1
+            t0 = time.time()
+            o.render(f, threads=threads, out=scratch)
+            dt = time.time() - t0
+            total_rows, total_s = rows, dt
+            if dt >= budget * 0.5 or rows >= args.res:
+                break
+            rows = min(args.res, max(rows * 2, int(rows * budget / max(dt, 1e-3) * 0.8)))
+        rays = total_rows * args.res * args.spp * args.spp
+        return rays / total_s / 1e6, total_rows, rays, total_s
+
+    v_all, rows_all, rays_all, s_all = timed(cores, budget_s * 0.55)
+    v_4, rows_4, rays_4, s_4 = timed(min(4, cores), budget_s * 0.45)
+    # a C# toolchain on the GPU box would let the genuine reference be timed: probe, never assume
+    csharp = [t for t in ("dotnet", "mono", "mcs", "csc") if shutil.which(t)]
+    cpu_model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu_model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": v_all, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "%d centred rows x %d cols of the same %dx%d frame (%d primary rays, %.1f s); C++ restatement of "
-                      "the reference algorithm (reference tree 15/25, row-block threads) -- real C# unavailable; "
-                      "tree build %.1f s excluded" % (total_rows, args.res, args.res, args.res, rays, total_s, build_s)}
+                      "the reference algorithm (reference tree 15/25, row-block threads, g++ -O2 -ffp-contract=off) -- real C# unavailable; "
+                      "tree build %.1f s excluded" % (rows_all, args.res, args.res, args.res, rays_all, s_all, build_s),
+            "threads_4": {"value": v_4, "threads": min(4, cores), "sample": "%d centred rows (%d primary rays, %.1f s)" % (rows_4, rays_4, s_4),
+                          "note": "rayTraceConcurrency's default (Renderer.cs:82)"},
+            "cpu_model": cpu_model,
+            "csharp_toolchain_on_this_box": csharp or None,
+            "csharp_note": ("found %s: the genuine C# reference could be built here, but its sources do not travel to the GPU box" % csharp) if csharp
+                           else "no dotnet / mono / mcs / csc on this box: the number is the C++ restatement of the reference algorithm"}
+
+
+def committed_profile():
+    """SQ counters / HBM traffic of this workload from the rocprofv3 passes committed under profiles/ (live PMC needs rocprofv3)."""
+    out = {"issue": None, "traffic": {}}
+    import csv
+    spath = os.path.join(PROFILE_DIR, "sq_counters_summary.csv")
+    if os.path.exists(spath):
+        try:
+            issue = {"source": os.path.relpath(spath, ROOT) + " (rocprofv3 --pmc SQ_*, separate passes, same workload)", "kernels": {}}
+            for r in csv.DictReader(open(spath)):
+                ns = float(r.get("_ns", 0) or 0)
+                if ns <= 0:
+                    continue
+                lane_ops = float(r.get("SQ_THREAD_CYCLES_VALU", 0) or 0)
+                issue["kernels"][r["kernel"]] = {
+                    "valu_busy_frac": float(r["valu_busy_frac_at_2.4GHz_1024_SIMDs"]),
+                    "active_lanes_per_valu_inst": float(r["active_lanes_per_valu_inst"]),
+                    "useful_lane_ops_per_s": lane_ops / (ns * 1e-9),
+                    "frac_of_valu_peak": lane_ops / (ns * 1e-9) / VALU_PEAK_LANE_OPS,
+                }
+            out["issue"] = issue
+        except Exception:
+            pass
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            out["traffic"] = json.load(open(tpath))
+        except Exception:
+            pass
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--res", type=int, default=4096)
     ap.add_argument("--tris", type=int, default=1000000)
     ap.add_argument("--shadows", type=int, default=100, help="area-light samples per hit (100 = reference; 0 = primary only; 1 = hard shadow)")
@@ -137,9 +204,13 @@ def main():
     ap.add_argument("--strip-rows", type=int, default=16)
     ap.add_argument("--device-build", action="store_true", help="build the BVH on the GPU (LBVH) instead of the host SAH builder")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (kernel times, counters, primary-only, surface passes)")
     ap.add_argument("--exact-shadow-tests", action="store_true", help="k_shadow_test (every pair in FP64) instead of the fp32-classified k_shadow_cls")
     ap.add_argument("--dbg", action="append", default=[], metavar="KEY=VALUE", help="sr_debug_set hook, e.g. --dbg 1=16 (SR_DBG_ROUND_CAP0 = 16)")
-    ap.add_argument("--verify", action="store_true", help="after timing: rank 0 re-renders the whole frame alone and compares it with the gathered one")
+    ap.add_argument("--in-library", action="store_true", help="single process: --gpus N devices behind sr_create_multi instead of one rank per GPU")
+    ap.add_argument("--same-device", action="store_true", help="with --in-library: list device 0 N times (rehearsal on a one-GPU box)")
+    ap.add_argument("--prelude-s", type=float, default=2.0, help="untimed seconds of continuous frames before the timed region (lets GPU-busy samplers see the GPU phase)")
+    ap.add_argument("--verify", action="store_true", help="after timing: rank 0 re-renders the whole frame alone and compares it with the one that arrived on the host")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
     args = ap.parse_args()
 
@@ -151,6 +222,7 @@ def main():
     ndev = torch.cuda.device_count()
     if ndev == 0:
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU implementation")
+    in_library = args.in_library and world == 1 and args.gpus > 1
     local_rank = local_rank % ndev            # (rehearsals with more ranks than GPUs share devices; the driver uses one rank per GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -160,10 +232,14 @@ def main():
         else:
             dist.init_process_group(args.backend)
 
-    # ---- scene resident in HBM (replicated on every rank: 128 MB of records) ----
+    # ---- scene resident in HBM (replicated on every GPU: 128 MB of records) ----
     v9, argb = sa.make_random_triangles(args.tris, 12345, space=1.0 - args.extent, extent=args.extent, origin=-0.5, opaque=True)
     bmin, bmax = np.array([-0.5] * 3), np.array([0.5] * 3)
-    g = sa.GpuScene(local_rank)
+    if in_library:
+        devices = [0] * args.gpus if args.same_device else [d % ndev for d in range(args.gpus)]
+        g = sa.GpuScene(devices=devices)
+    else:
+        g = sa.GpuScene(local_rank)
     g.set_triangles(v9, argb, bmin, bmax)
     if args.exact_shadow_tests:
         g.debug_set(sa._lib.DBG_EXACT_SHADOW_TESTS, 1)
@@ -175,176 +251,200 @@ def main():
             on_device=args.device_build and args.mode == "bvh")
     build_s = time.time() - t0
 
+    n_gpus = args.gpus if (world > 1 or in_library) else 1
     strips = (args.strip_rows, world, rank) if world > 1 else None
     frame = make_frame(args, strips)
     npix = g.pixel_count(frame)
+    full_px = args.res * args.res
     stream = torch.cuda.current_stream(dev)
-    sg = StripGather(args.res, args.res, args.strip_rows, world, rank, dev) if world > 1 else None
-    local = sg.local if sg else torch.empty(npix, dtype=torch.int32, device=dev)
+    copy_stream = torch.cuda.Stream(dev)
+    sg = [StripGather(args.res, args.res, args.strip_rows, world, rank, dev) for _ in range(2)] if world > 1 else None
     if sg:
-        assert sg.counts[rank] == npix
+        assert sg[0].counts[rank] == npix
+        surfaces = [s.full for s in sg]                                # rank 0: the gathered frames
+    else:
+        surfaces = [torch.empty(npix, dtype=torch.int32, device=dev) for _ in range(2)]
+    host = [torch.empty(full_px, dtype=torch.int32).pin_memory() for _ in range(2)] if rank == 0 else None
+    rendered = [torch.cuda.Event() for _ in range(2)]
+    copied = [torch.cuda.Event() for _ in range(2)]
+    copied_once = [False, False]
+    state = {"k": 0, "readback": True}
 
     def step():
+        k = state["k"] % 2
+        state["k"] += 1
         if args.static_shadows:
             g.reset_shadow_cache()                                   # every step generates the whole cache again
-        g.render_device(frame, local.data_ptr(), stream.cuda_stream)
+        if state["readback"] and copied_once[k]:
+            stream.wait_event(copied[k])                             # surface k is free once its last read-back has finished
+        target = sg[k].local if sg else surfaces[k]
+        g.render_device(frame, target.data_ptr(), stream.cuda_stream)
         if sg:
-            sg.exchange()                                             # RCCL gather over xGMI + de-interleave on rank 0
+            sg[k].exchange()                                          # RCCL gather over xGMI + de-interleave on rank 0
+        if rank == 0 and state["readback"]:
+            rendered[k].record(stream)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(rendered[k])
+                host[k].copy_(surfaces[k].view(-1), non_blocking=True)   # pinned: a real asynchronous D2H
+                copied[k].record(copy_stream)
+            copied_once[k] = True
+
+    def timed(steps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize(dev)                                  # all streams of the device: the last frame is on the host
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        return dt
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
     torch.cuda.synchronize(dev)
-    g.reset_kernel_times()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    # per-kernel device time: one HIP event pair per launch on the launch stream, recorded inside the library; average =
-    # total / launches.  The timed steps above run the frame as two concurrent halves (two internal streams), so their
-    # kernels share the GPU pairwise; the durations the roofline uses come from K more frames rendered as ONE pipeline
-    # (SR_F_NO_SPLIT: same kernels, same work per frame, no overlap), timed as a whole for reference
-    frame_ns = sa.Frame.from_buffer_copy(bytes(frame))
-    frame_ns.flags |= sa._lib.F_NO_SPLIT
-    if frame.area_light_offsets:
-        frame_ns.area_light_offsets = frame.area_light_offsets
-    g.debug_set(sa._lib.DBG_KERNEL_TIMING, 1)                         # event pairs around every launch: only in this extra pass
-    g.render_device(frame_ns, local.data_ptr(), stream.cuda_stream)
-    torch.cuda.synchronize(dev)
-    g.reset_kernel_times()
-    t1 = time.perf_counter()
-    for _ in range(args.steps):
-        g.render_device(frame_ns, local.data_ptr(), stream.cuda_stream)
-    torch.cuda.synchronize(dev)
-    ms_unsplit = (time.perf_counter() - t1) / args.steps * 1e3
-    kt = {k: (ms / max(1, n), n) for k, (ms, n) in g.kernel_times().items()}
-    g.debug_set(sa._lib.DBG_KERNEL_TIMING, -1)
+    if args.prelude_s > 0 and world == 1:                            # untimed: keeps the GPU visibly busy for a sampler
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < args.prelude_s:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize(dev)
+    elapsed = timed(args.steps)
 
     primary_rays = args.res * args.res * args.spp * args.spp
     value = primary_rays * args.steps / elapsed / 1e6
     ms_per_step = elapsed / args.steps * 1e3
+    last_host_frame = host[(state["k"] - 1) % 2].numpy().copy() if rank == 0 else None
 
     out = None
     if rank == 0:
-        # ---- roofline inputs: deterministic device counters of one (untimed) stats pass over this rank's share ----
-        host_px = np.zeros(npix, dtype=np.int32)
-        g.render(frame, out=host_px, stats=True)
-        rs = g.ray_stats().astype(np.float64)
-        # algorithmic bytes per FRAME of each kernel, at wave granularity (what a launch must move at least once):
-        #   k_primary      per ray (lanes walk independently): 4 B pixel + 64 B/node visit + 128 B/triangle test (+64 B queue record per hit)
-        #   k_shaft        per hit point: 64 B queue record + 64 B/node visit + 64 B/slab record + 4 B/list entry written
-        #   k_shadow(_test) per hit point: 64 B queue record + 4 B count + per staged triangle (4 B list entry + 128 B record) + 8 B pixel RMW
-        per_ray_touch = S_PIX * (npix * 1.0) + (rs[2] + rs[6]) * S_NODE + (rs[1] + rs[5]) * S_TRI     # SURVEY 8d figure (per-lane touches)
-        algo = {
-            "k_primary": S_PIX * npix + rs[2] * S_NODE + rs[1] * S_TRI + 64.0 * (rs[4] / max(1, args.shadows) if args.shadows else 0),
-            "k_shaft": rs[11] * 64.0 + rs[6] * S_NODE + rs[10] * 64.0 + rs[8] * 4.0,
-            # k_shadow_cls reads the 64-byte fp32 TriSlab of a candidate (k_shadow_test, the FP64 cross-check, its 128-byte record)
-            "k_shadow": rs[9] * (64.0 + 4.0 + 8.0) + rs[8] * ((S_TRI if args.exact_shadow_tests else 64.0) + 4.0),
-            "k_render": per_ray_touch,
-        }
-        tot = {k: v[0] * v[1] for k, v in kt.items()}                 # total ms per kernel over the timed steps
-        fam = lambda k: "k_shaft" if k.startswith("k_shaft") else ("k_shadow" if k.startswith("k_shadow") else k)
-        fam_ms = {}
-        for k, v in tot.items():
-            fam_ms[fam(k)] = fam_ms.get(fam(k), 0.0) + v / args.steps  # ms per frame
-        dom = max(fam_ms.items(), key=lambda kv: kv[1]) if fam_ms else ("none", float("nan"))
-        dom_ms = dom[1]
-        algo_bytes = algo.get(dom[0], per_ray_touch)
-        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else float("nan")
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("%s_%d_%d_%d" % (args.mode, args.tris, args.res, args.shadows), {}).get(dom[0])
-            except Exception:
-                traffic = None
-        # what actually bounds the kernels: SQ counters of the committed profile of this workload (separate rocprofv3 --pmc passes)
-        issue = None
-        spath = os.path.join(ROOT, "profiles", "r01d_pipeline", "sq_counters_summary.csv")
-        if os.path.exists(spath) and traffic is not None:
-            try:
-                import csv
-                issue = {"source": "profiles/r01d_pipeline/sq_counters_summary.csv (rocprofv3 --pmc SQ_*, same workload)",
-                         "valu_busy_frac": {}, "active_lanes_per_valu_inst": {}, "wait_any_frac_of_wave_cycles": {}}
-                for r in csv.DictReader(open(spath)):
-                    if r["kernel"] in ("k_primary", "k_shaft", "k_shadow_test"):
-                        issue["valu_busy_frac"][r["kernel"]] = float(r["valu_busy_frac_at_2.4GHz_1024_SIMDs"])
-                        issue["active_lanes_per_valu_inst"][r["kernel"]] = float(r["active_lanes_per_valu_inst"])
-                        issue["wait_any_frac_of_wave_cycles"][r["kernel"]] = float(r["SQ_WAIT_ANY"]) / float(r["SQ_WAVE_CYCLES"])
-            except Exception:
-                issue = None
-        # PCIe-inclusive frame time (never `value`): one D2H of the frame
-        t1 = time.perf_counter()
-        local.cpu()
-        d2h_ms = (time.perf_counter() - t1) * 1e3
         out = {
-            "metric": "Mrays/s (primary rays) at %dx%d, shading + %s, %s" % (
+            "metric": "Mrays/s (primary rays) at %dx%d, shading + %s, %s, frame read back to the host" % (
                 args.res, args.res,
                 "100-sample soft shadows" if args.shadows == 100 else ("no shadows" if args.shadows == 0 else "%d-sample shadows" % args.shadows),
                 {"bvh": "own BVH", "ref": "reference tree", "brute": "brute force"}[args.mode]),
-            "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "%d random triangles (System.Random seed 12345, extent %g, unit cube) + BVH, %dx%d, "
                                    "spp %d, shading + %d shadow samples/hit, pose yaw135/pitch-22/depth %.1f" % (
                                        args.tris, args.extent, args.res, args.res, args.spp * args.spp, args.shadows, args.depth),
-                       "trace_mode": args.mode, "parallelism": "rows x%d (interleaved %d-row strips)" % (world, args.strip_rows)},
-            "rays_rank0": {"primary": rs[0], "shadow": rs[4], "tri_tests": rs[1] + rs[5], "node_visits": rs[2] + rs[6],
-                           "primary_plus_shadow_Mrays_per_s": ((rs[0] + rs[4]) / (ms_per_step * 1e-3) / 1e6) if world == 1 else None},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS if achieved == achieved else None, "traffic": traffic,
-                         "kernel": dom[0], "kernel_ms_per_frame": dom_ms, "algorithmic_bytes_per_frame": algo_bytes,
-                         "launches_per_frame": sum(v[1] for k, v in kt.items() if fam(k) == dom[0]) / args.steps,
-                         "all_kernels_ms_per_frame": fam_ms,
-                         "all_kernels_algorithmic_GBs": {k: algo.get(k, 0.0) / (v * 1e-3) / 1e9 for k, v in fam_ms.items() if v > 0},
-                         "per_ray_touch_bytes_per_frame": per_ray_touch, "issue_bound": issue,
-                         "note": "achieved = wave-granular algorithmic bytes of the dominant kernel family per frame / its device time per frame "
-                                 "(HIP event pairs around every launch of K frames rendered as one pipeline, SR_F_NO_SPLIT, so that no two kernels share "
-                                 "the GPU; `value` is measured with the default two concurrent half-frame pipelines).  The scene (128 MB records + 21 MB BVH + 64 MB slabs) is cache "
-                                 "resident and the kernels are FP64-issue / latency bound, not HBM bound; per_ray_touch is SURVEY 8d's "
-                                 "per-lane figure (4 B + 64 B/node + 128 B/triangle test per ray)"},
-            "kernels_ms": {k: v[0] for k, v in kt.items()}, "kernel_launches": {k: v[1] for k, v in kt.items()},
-            "ms_per_step_one_pipeline": ms_unsplit,
-            "pipeline_counters_last_band": g.debug_counters(), "device_counters": [float(x) for x in rs],
-            "shadow_pairs": {"classified_fp32": rs[12], "decided_fp64": rs[13], "fp64_fraction": (rs[13] / rs[12]) if rs[12] else None},
-            "build_s": build_s, "d2h_ms": d2h_ms,
+                       "trace_mode": args.mode,
+                       "parallelism": ("rows x%d (interleaved %d-row strips, %s)" % (
+                           n_gpus, args.strip_rows, "one process, sr_create_multi" if in_library else "one process per GPU + RCCL gather")) if n_gpus > 1 else "one GPU",
+                       "readback": "every frame copied to pinned host memory inside the timed region (the copy of frame k overlaps frame k+1)"},
+            "build_s": build_s,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, v9, argb, bmin, bmax)
-    if args.verify and rank == 0:
-        ref = np.zeros(args.res * args.res, dtype=np.int32)
-        g.render(make_frame(args), out=ref, stats=False)
-        got = (sg.full if sg else local).cpu().numpy().reshape(-1)
-        out["verify"] = {"full_frame_equal": bool(np.array_equal(got, ref)), "crc": int(np.bitwise_xor.reduce(ref.view(np.uint32)))}
-        assert out["verify"]["full_frame_equal"], "gathered frame differs from the single-process frame"
-    # ---- the same frame without ShadowMethod (rayTraceShadows = false): the "primary rays only" rate, same scene/pose ----
-    if world == 1 and args.shadows > 0:
-        import copy
-        a0 = copy.copy(args)
-        a0.shadows = 0
-        f0 = make_frame(a0)
-        for _ in range(max(1, args.warmup)):
-            g.render_device(f0, local.data_ptr(), stream.cuda_stream)
+
+    extras = world == 1 and not in_library and not args.no_extras
+    if extras:
+        # ---- the same steps with the frame left in HBM (no read-back) ----
+        state["readback"] = False
+        for _ in range(2):
+            step()
+        dt = timed(args.steps)
+        out["hbm_resident"] = {"value": primary_rays * args.steps / dt / 1e6, "unit": "Mrays/s", "ms_per_step": dt / args.steps * 1e3,
+                               "note": "frame stays in HBM (round-1 definition of `value`)"}
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        for _ in range(args.steps):
-            g.render_device(f0, local.data_ptr(), stream.cuda_stream)
+        host[0].copy_(surfaces[0].view(-1))                            # one blocking D2H into pinned memory, for reference
         torch.cuda.synchronize(dev)
-        dt0 = (time.perf_counter() - t1) / args.steps
-        out["primary_only"] = {"value": primary_rays / dt0 / 1e6, "unit": "Mrays/s", "ms_per_step": dt0 * 1e3,
-                               "note": "same scene, pose and resolution with rayTraceShadows = false (shading on): primary rays only"}
-    # ---- the two surface passes of Renderer.Render() (PostProcessImage / AntiAliasImage) on the resident frame ----
-    if world == 1 and rank == 0:
+        out["d2h_ms"] = (time.perf_counter() - t1) * 1e3
+
+        # ---- per-kernel device time: HIP event pairs around every launch (opt-in), frames rendered as ONE pipeline
+        #      (SR_F_NO_SPLIT: same kernels, same work per frame, no two kernels sharing the GPU) ----
+        ksteps = min(args.steps, 5)
+        frame_ns = sa.Frame.from_buffer_copy(bytes(frame))
+        frame_ns.flags |= sa._lib.F_NO_SPLIT
+        if frame.area_light_offsets:
+            frame_ns.area_light_offsets = frame.area_light_offsets
+        local = surfaces[0]
+        g.debug_set(sa._lib.DBG_KERNEL_TIMING, 1)
+        g.render_device(frame_ns, local.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        g.reset_kernel_times()
+        t1 = time.perf_counter()
+        for _ in range(ksteps):
+            g.render_device(frame_ns, local.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        ms_unsplit = (time.perf_counter() - t1) / ksteps * 1e3
+        kt = {k: (ms / max(1, n), n) for k, (ms, n) in g.kernel_times().items()}     # average ms per launch, launches
+        g.debug_set(sa._lib.DBG_KERNEL_TIMING, -1)
+
+        # ---- roofline inputs: deterministic device counters of one (untimed) stats pass ----
+        host_px = np.zeros(npix, dtype=np.int32)
+        g.render(frame_ns, out=host_px, stats=True)
+        rs = g.ray_stats().astype(np.float64)
+        out["frame_crc"] = int(np.bitwise_xor.reduce(host_px.view(np.uint32)))
+        out["readback_equals_blocking_render"] = bool(np.array_equal(last_host_frame, host_px))
+        # algorithmic bytes per LAUNCH (one pipeline = one launch per frame of every kernel) = what the launch must move at
+        # least once:
+        #   k_primary (packet walk)  4 B pixel per ray + 64 B per node a lane's ray needed + 64 B per camera-cone record it
+        #                            consulted (lane counts: an upper bound of the wave-level traffic) + 64 B queue record per hit
+        #   k_shaft (packet walk)    per hit point 64 B queue record + 4 B count; per WAVE 64 B/node + 64 B/TriSlab; 4 B per list entry
+        #   k_shadow (k_shadow_cls)  per hit point 64 B + 4 B + 8 B pixel RMW; per candidate 4 B list entry + 64 B TriSlab
+        pkt_nodes, pkt_slabs = rs[6] - rs[14], rs[10] - rs[15]
+        algo = {
+            "k_primary": S_PIX * npix + rs[2] * S_NODE + rs[1] * S_SLAB + 64.0 * rs[11],
+            "k_shaft": rs[11] * (64.0 + 4.0) + pkt_nodes * S_NODE + pkt_slabs * S_SLAB + rs[8] * 4.0,
+            "k_shaft_round2": rs[14] * S_NODE + rs[15] * S_SLAB,
+            "k_shadow": rs[9] * (64.0 + 4.0 + 8.0) + rs[8] * ((S_TRI if args.exact_shadow_tests else S_SLAB) + 4.0),
+        }
+        per_ray_touch = S_PIX * npix + (rs[2] + rs[6]) * S_NODE + (rs[1] + rs[5]) * S_TRI     # SURVEY 8d's per-lane figure
+        dom = max(kt.items(), key=lambda kv: kv[1][0]) if kt else ("none", (float("nan"), 0))
+        dom_name, dom_ms = dom[0], dom[1][0]
+        algo_bytes = algo.get(dom_name, float("nan"))
+        achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else float("nan")
+        prof = committed_profile()
+        tkey = "%s_%d_%d_%d" % (args.mode, args.tris, args.res, args.shadows)
+        traffic = (prof["traffic"].get(tkey) or {}).get(dom_name)
+        prof_kernels = (prof["issue"] or {}).get("kernels") or {}
+        prof_name = {"k_shaft": "k_shaft_pkt", "k_shadow": "k_shadow_cls"}.get(dom_name, dom_name)
+        issue_achieved = prof_kernels.get(prof_name, {}).get("useful_lane_ops_per_s")
+        out.update({
+            "rays": {"primary": rs[0], "shadow": rs[4], "primary_plus_shadow_Mrays_per_s": (rs[0] + rs[4]) / (ms_per_step * 1e-3) / 1e6},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS if achieved == achieved else None, "traffic": traffic,
+                         "kernel": dom_name, "kernel_ms_per_launch": dom_ms, "launches_timed": dom[1][1], "algorithmic_bytes_per_launch": algo_bytes,
+                         "all_kernels_ms_per_launch": {k: v[0] for k, v in kt.items()},
+                         "all_kernels_algorithmic_GBs": {k: algo[k] / (v[0] * 1e-3) / 1e9 for k, v in kt.items() if k in algo and v[0] > 0},
+                         "per_ray_touch_bytes_per_frame": per_ray_touch,
+                         "note": "achieved = algorithmic bytes of ONE launch of the dominant kernel / its average launch duration (HIP event pairs on the "
+                                 "launch stream, frames rendered as one pipeline so that no two kernels share the GPU).  The scene (128 MB records + 21 MB BVH + "
+                                 "2 x 64 MB fp32 records) is cache resident; the kernels are bound by instruction issue (see roofline_issue), not by HBM"},
+            "roofline_issue": {"bound": "valu_issue", "achieved": issue_achieved, "peak": VALU_PEAK_LANE_OPS, "unit": "lane-instructions/s",
+                               "frac": (issue_achieved / VALU_PEAK_LANE_OPS) if issue_achieved else None, "kernel": prof_name,
+                               "peak_derivation": "256 CUs x 4 SIMDs x 16 lanes/cycle x 2.4 GHz (an FMA counts once; packed fp32 counts once per lane)",
+                               "kernels": prof_kernels or None, "source": (prof["issue"] or {}).get("source"),
+                               "note": "achieved = SQ_THREAD_CYCLES_VALU (active lanes summed over VALU instructions) / kernel time of the dominant kernel, from the "
+                                       "committed rocprofv3 passes of this workload"},
+            "ms_per_step_one_pipeline": ms_unsplit,
+            "pipeline_counters": g.debug_counters(), "device_counters": [float(x) for x in rs],
+            "shadow_pairs": {"classified_fp32": rs[12], "decided_fp64": rs[13], "fp64_fraction": (rs[13] / rs[12]) if rs[12] else None},
+        })
+
+        # ---- the same frame without ShadowMethod (rayTraceShadows = false): the "primary rays only" rate ----
+        if args.shadows > 0:
+            a0 = copy.copy(args)
+            a0.shadows = 0
+            f0 = make_frame(a0)
+            for _ in range(2):
+                g.render_device(f0, local.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                g.render_device(f0, local.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize(dev)
+            dt0 = (time.perf_counter() - t1) / args.steps
+            out["primary_only"] = {"value": primary_rays / dt0 / 1e6, "unit": "Mrays/s", "ms_per_step": dt0 * 1e3,
+                                   "note": "same scene, pose and resolution with rayTraceShadows = false (shading on), frame left in HBM"}
+        # ---- the two surface passes of Renderer.Render() (PostProcessImage / AntiAliasImage) on the resident frame ----
         n = args.res * args.res
         aa_dst = torch.empty(n // 4, dtype=torch.int32, device=dev)
         g.debug_set(sa._lib.DBG_KERNEL_TIMING, 1)
@@ -355,6 +455,7 @@ def main():
             g.anti_alias_device(local.data_ptr(), args.res // 2, args.res // 2, 2, aa_dst.data_ptr(), stream.cuda_stream)
         torch.cuda.synchronize(dev)
         kp = g.kernel_times()
+        g.debug_set(sa._lib.DBG_KERNEL_TIMING, -1)
         pp_ms = kp["k_post_process"][0] / reps
         aa_ms = kp["k_anti_alias"][0] / reps
         out["surface_passes"] = {
@@ -362,6 +463,18 @@ def main():
             "anti_alias_2x": {"ms": aa_ms, "achieved_GBps": 5.0 * n / (aa_ms * 1e-3) / 1e9, "bytes": "4 B/source pixel + 4 B/destination pixel"},
             "peak_GBps": 8000.0,
         }
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, v9, argb, bmin, bmax)
+    if args.verify and rank == 0:
+        ref_scene = g
+        if in_library:
+            ref_scene = sa.GpuScene(0)
+            ref_scene.set_triangles(v9, argb, bmin, bmax)
+            ref_scene.build((sa.MODE_BVH,))
+        ref = np.zeros(args.res * args.res, dtype=np.int32)
+        ref_scene.render(make_frame(args), out=ref, stats=False)
+        out["verify"] = {"full_frame_equal": bool(np.array_equal(last_host_frame, ref)), "crc": int(np.bitwise_xor.reduce(ref.view(np.uint32)))}
+        assert out["verify"]["full_frame_equal"], "the frame that arrived on the host differs from the single-GPU frame"
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

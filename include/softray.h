@@ -251,7 +251,8 @@ int  sr_kernel_times(sr_scene*, sr_kernel_time* out, int32_t cap);
  * visited, leaf nodes visited}; [4..7] the same for secondary (shadow) rays -- on the shaft path [6],[7] are the shaft
  * walks' nodes / leaves; [8] triangle records staged through LDS by k_shadow_test, [9] hit points it processed,
  * [10] fp32 slab records read by k_shaft, [11] hit points it walked, [12] (sample, triangle) pairs k_shadow_test classified
- * in fp32, [13] pairs it had to decide with the exact FP64 test, [14..15] reserved.  These are the counters the roofline's
+ * in fp32, [13] pairs it had to decide with the exact FP64 test, [14] / [15] the part of [6] / [10] that came from private per-lane
+ * shaft walks (later rounds) rather than from the packet walk.  These are the counters the roofline's
  * algorithmic bytes are priced from (DESIGN.md "Measurement"). */
 int  sr_last_ray_stats(const sr_scene*, uint64_t out[16]);
 

@@ -575,6 +575,8 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
     if (STATS) {
         uint32_t a = wave_sum(nodes), b = wave_sum(leaves), c2 = wave_sum(slabs), d2 = wave_sum(live ? 1u : 0u);
         block_stat_add(&stats[6], &stats[7], &stats[10], &stats[11], a, b, c2, d2);
+        // private walks (later rounds) once more on their own, so that the packet kernel's share of [6], [10], [11] can be told apart
+        block_stat_add(&stats[14], &stats[15], &stats[14], &stats[15], a, c2, 0u, 0u);
     }
 }
 
