@@ -224,6 +224,13 @@ int  sr_trace_rays(sr_scene*, int32_t target, int64_t n, const double* starts, c
                    uint8_t* hit, double* ray_frac, double* pos, double* normal, uint32_t* color,
                    int32_t* tri_index, int32_t* counters);
 
+/* ShadingMethod.IntersectRay's colour step in batch (ShadingMethod.cs:36-68 -> CalcLighting :110-177): for n recorded
+ * intersections out[i] = ModulatePackedColor(color[i], (byte)(255 * intensity)) with the frame's transform and lights (only the
+ * matrices, position_z, fov_depth, lights, ambient, shininess and the POINT_LIGHT / SPECULAR flags of `frame` are read).
+ * Host arrays.  The decorator's arithmetic on its own -- Math.Pow included -- without a traversal in front of it. */
+int  sr_shade_points(sr_scene*, const sr_frame* frame, int64_t n, const double* pos, const double* normal, const uint32_t* color,
+                     uint32_t* out);
+
 /* Instance.InitRender matrices (Instance.cs:134-135, Matrix.cs:74-169): T = Trans(P)*Roll*Pitch*Yaw,
  * T^-1 = Yaw(-)*Pitch(-)*Roll(-)*Trans(-P); rows 0..2, row-major 3x4. */
 void sr_instance_matrices(const double position[3], double yaw, double pitch, double roll,

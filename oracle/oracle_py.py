@@ -80,6 +80,8 @@ def lib():
         L.orc_scene_tree_stats.argtypes = [vp, vp]
         L.orc_scene_reset_shadow_cache.argtypes = [vp]
         L.orc_render.restype = i32; L.orc_render.argtypes = [vp, vp, vp, vp, i32]
+        L.orc_shade_points.restype = i32
+        L.orc_shade_points.argtypes = [vp, i64, vp, vp, vp, vp, i32]
         L.orc_trace.restype = i32
         L.orc_trace.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
         L.orc_instance_matrices.argtypes = [vp, dbl, dbl, dbl, vp, vp]
@@ -241,6 +243,17 @@ class Scene:
 
 # ---- surface passes after the raytrace (numpy restatement; Engine3D/Renderer.cs:765-767) ----
 STYLE_STANDARD, STYLE_COLOR_SHUFFLE, STYLE_NEGATIVE, STYLE_DEPTH_SMOOTH, STYLE_DEPTH_BANDED = 0, 1, 2, 3, 4
+
+
+def shade_points(frame, pos, normal, color, threads=1):
+    """ShadingMethod.IntersectRay's colour step for recorded intersections (orc_shade_points)."""
+    pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+    normal = np.ascontiguousarray(normal, dtype=np.float64).reshape(-1, 3)
+    color = np.ascontiguousarray(color, dtype=np.uint32)
+    out = np.zeros(pos.shape[0], dtype=np.uint32)
+    rc = lib().orc_shade_points(C.byref(frame), pos.shape[0], _p(pos), _p(normal), _p(color), _p(out), int(threads))
+    assert rc == 0
+    return out
 
 
 def post_process(pixels, style, background_color=0):

@@ -998,6 +998,39 @@ void orc_area_light_offsets(int32_t seed, int32_t count, double* out3) {
     for (int i = 0; i < count; i++) { out3[3 * i] = v[i].x; out3[3 * i + 1] = v[i].y; out3[3 * i + 2] = v[i].z; }
 }
 
+/* ShadingMethod.IntersectRay's colour step (ShadingMethod.cs:36-68) for recorded intersections: pure arithmetic, no
+ * traversal -- what the GPU-vs-CPU census of Math.Pow (ocml vs glibc) compares over >= 1e7 surface points */
+int orc_shade_points(const orc_frame* f, int64_t n, const double* pos, const double* normal, const uint32_t* color, uint32_t* out, int32_t threads) {
+    InstanceXf xf;
+    for (int r = 0; r < 3; r++)
+        for (int c = 0; c < 4; c++) { xf.t[r][c] = f->transform[r * 4 + c]; xf.it[r][c] = f->inv_transform[r * 4 + c]; }
+    xf.positionZ = f->position_z;
+    xf.fovDepth = f->fov_depth;
+    SceneLight light;
+    light.directionalLightDir_View = V(f->light_dir_view[0], f->light_dir_view[1], f->light_dir_view[2]);
+    light.positionalLightPos_View = V(f->light_pos_view[0], f->light_pos_view[1], f->light_pos_view[2]);
+    light.directionalLightDir_Model = xf.TransformDirectionReverse(light.directionalLightDir_View);
+    light.positionalLightPos_Model = xf.TransformPosFromView(light.positionalLightPos_View);
+    light.pointLighting = (f->flags & ORC_F_POINT_LIGHT) != 0;
+    light.specularLighting = (f->flags & ORC_F_SPECULAR) != 0;
+    light.ambientLight_intensity = f->ambient;
+    light.specularLight_shininess = f->shininess;
+    int nt = std::max(1, (int)threads);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < nt; t++) {
+        pool.emplace_back([&, t]() {
+            for (int64_t i = (n * t) / nt; i < (n * (t + 1)) / nt; i++) {
+                Vec pos_View = xf.TransformPosToView(V(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]));
+                Vec normal_View = xf.TransformDirection(V(normal[3 * i], normal[3 * i + 1], normal[3 * i + 2]));
+                double intensity = CalcLightingIntensity(light, pos_View, normal_View);
+                out[i] = ModulatePackedColor(color[i], ToByte(255 * intensity));
+            }
+        });
+    }
+    for (auto& th : pool) th.join();
+    return 0;
+}
+
 int orc_render(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t stats[4], int32_t threads) {
     if (!s->haveBox || s->tris.empty()) return -3;               /* no model pinned: Renderer.cs:736-739 */
     if (f->trace_mode == ORC_MODE_REF_TREE && !s->haveTree) return -4;

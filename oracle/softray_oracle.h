@@ -103,6 +103,11 @@ void orc_scene_reset_shadow_cache(orc_scene*);   /* a new Renderer / ShadowMetho
  * deterministic sums, not the reference's racy per-block counters).  threads<=0 => 1. */
 int  orc_render(const orc_scene*, const orc_frame*, int32_t* pixels, uint64_t stats[4], int32_t threads);
 
+/* ShadingMethod.IntersectRay's colour step (ShadingMethod.cs:36-68, CalcLighting :110-177) for n recorded intersections:
+ * out[i] = ModulatePackedColor(color[i], (byte)(255 * intensity(pos[i], normal[i]))) with the frame's light / transform. */
+int  orc_shade_points(const orc_frame*, int64_t n, const double* pos, const double* normal, const uint32_t* color,
+                      uint32_t* out, int32_t threads);
+
 /* IRayIntersectable.IntersectRay in batch (IRayIntersectable.cs:31-48).
  * target: 0 = triangles brute (GeometryCollection), 1 = tree, 2 = root geometry of the chain
  * (extra geometry + tree, Renderer.cs:1545-1549), 3 = ORC_MODE_NEAREST semantics.

@@ -30,7 +30,7 @@ SYMBOLS = [
     "sr_default_fov_depth", "sr_area_light_offsets", "sr_load_3ds", "sr_num_triangles", "sr_get_triangles",
     "sr_reset_kernel_times", "sr_kernel_times", "sr_last_ray_stats", "sr_make_random_triangles", "sr_debug_counters", "sr_last_error", "sr_abi_version",
     "sr_post_process", "sr_post_process_device", "sr_anti_alias", "sr_anti_alias_device", "sr_reset_shadow_cache",
-    "sr_debug_set", "sr_bvh_stats", "sr_create_multi", "sr_device_count",
+    "sr_debug_set", "sr_bvh_stats", "sr_create_multi", "sr_device_count", "sr_shade_points",
 ]
 # sr_debug_set keys (include/softray.h)
 (DBG_BAND_SAMPLES, DBG_ROUND_CAP0, DBG_ROUND_CAP1, DBG_SPLIT, DBG_FB_RAY_CAP, DBG_BVH_LEAF, DBG_KERNEL_SWITCH,
@@ -130,6 +130,7 @@ def lib():
     L.sr_bvh_stats.restype = i32; L.sr_bvh_stats.argtypes = [vp, vp]
     L.sr_create_multi.restype = i32; L.sr_create_multi.argtypes = [vp, i32, C.POINTER(vp)]
     L.sr_device_count.restype = i32; L.sr_device_count.argtypes = [vp]
+    L.sr_shade_points.restype = i32; L.sr_shade_points.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.sr_last_error.restype = C.c_char_p; L.sr_last_error.argtypes = []
     L.sr_abi_version.restype = i32; L.sr_abi_version.argtypes = []
     _lib = L

@@ -982,6 +982,26 @@ int sr_trace_rays(sr_scene* s, int32_t target, int64_t n, const double* starts, 
     return SR_OK;
 }
 
+int sr_shade_points(sr_scene* s, const sr_frame* f, int64_t n, const double* pos, const double* normal, const uint32_t* color, uint32_t* out) {
+    if (s && !s->parts.empty()) s = s->parts[0];
+    if (!s || n < 0 || (n > 0 && (!pos || !normal || !color || !out))) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_shade_points");
+    int rc = validate_frame(f);
+    if (rc) return rc;
+    if ((rc = use_device(s))) return rc;
+    if (n == 0) return SR_OK;
+    sr::FrameConst fc;
+    if ((rc = prepare_frame(s, f, fc))) return rc;
+    size_t sizes[4] = {(size_t)n * 24, (size_t)n * 24, (size_t)n * 4, (size_t)n * 4};
+    for (int i = 0; i < 4; ++i) SR_HIP(s->d_io[i].reserve(sizes[i]));
+    SR_HIP(hipMemcpy(s->d_io[0].p, pos, sizes[0], hipMemcpyHostToDevice));
+    SR_HIP(hipMemcpy(s->d_io[1].p, normal, sizes[1], hipMemcpyHostToDevice));
+    SR_HIP(hipMemcpy(s->d_io[2].p, color, sizes[2], hipMemcpyHostToDevice));
+    SR_HIP(sr::launch_shade_points(fc, n, (const double*)s->d_io[0].p, (const double*)s->d_io[1].p, (const uint32_t*)s->d_io[2].p, (uint32_t*)s->d_io[3].p, nullptr));
+    SR_HIP(hipStreamSynchronize(nullptr));
+    SR_HIP(hipMemcpy(out, s->d_io[3].p, sizes[3], hipMemcpyDeviceToHost));
+    return SR_OK;
+}
+
 void sr_instance_matrices(const double position[3], double yaw, double pitch, double roll, double transform[12], double inv_transform[12]) {
     sr::instance_matrices(position, yaw, pitch, roll, transform, inv_transform);
 }

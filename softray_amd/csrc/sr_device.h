@@ -116,5 +116,6 @@ struct TraceLaunch {
     hipStream_t stream;
 };
 hipError_t launch_trace(const TraceLaunch& L);
+hipError_t launch_shade_points(const FrameConst& fc, long long n, const double* pos, const double* nrm, const uint32_t* color, uint32_t* out, hipStream_t stream);
 
 }  // namespace sr

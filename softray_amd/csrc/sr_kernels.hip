@@ -215,6 +215,20 @@ static hipError_t launch_trace_m(const TraceLaunch& L) {
     return hipGetLastError();
 }
 
+// ShadingMethod.IntersectRay's colour step for recorded intersections (sr_shade_points): one lane per point
+__global__ __launch_bounds__(256) void k_shade_points(FrameConst fc, long long n, const double* __restrict__ pos, const double* __restrict__ nrm,
+                                                      const uint32_t* __restrict__ color, uint32_t* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[i] = shade(fc, mk(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), mk(nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2]), color[i]);
+}
+
+hipError_t launch_shade_points(const FrameConst& fc, long long n, const double* pos, const double* nrm, const uint32_t* color, uint32_t* out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_shade_points, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fc, n, pos, nrm, color, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_trace(const TraceLaunch& L) {
     switch (L.mode) {
         case MODE_REF: return launch_trace_m<MODE_REF>(L);

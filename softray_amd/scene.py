@@ -167,6 +167,15 @@ class GpuScene:
         n = _lib.lib().sr_kernel_times(self._h, arr, 16)
         return {arr[i].name.decode(): (float(arr[i].ms), int(arr[i].launches)) for i in range(n)}
 
+    def shade_points(self, frame, pos, normal, color):
+        """ShadingMethod.IntersectRay's colour step for recorded intersections (sr_shade_points)."""
+        pos = np.ascontiguousarray(pos, dtype=np.float64).reshape(-1, 3)
+        normal = np.ascontiguousarray(normal, dtype=np.float64).reshape(-1, 3)
+        color = np.ascontiguousarray(color, dtype=np.uint32)
+        out = np.zeros(pos.shape[0], dtype=np.uint32)
+        _check(_lib.lib().sr_shade_points(self._h, C.byref(frame), pos.shape[0], _p(pos), _p(normal), _p(color), _p(out)))
+        return out
+
     # ---- IRayIntersectable.IntersectRay, batched ----
     def trace(self, target, starts, dirs, counters=False):
         starts = np.ascontiguousarray(starts, dtype=np.float64).reshape(-1, 3)
