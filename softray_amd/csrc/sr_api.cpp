@@ -728,7 +728,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
     }
     if (!s) return fail(SR_ERR_INVALID_ARG, "scene is NULL");
     if (!s->have_model) return fail(SR_ERR_NO_MODEL, "sr_build before sr_set_triangles");
-    // leaves are packed as (first record | count << 28) and traversal stack words as (node | bound << bits): 2^28 records / 2^26 nodes
+    // leaves are packed as (first record | count << 27) and traversal stack words as (node | bound << bits): 2^28 records / 2^26 nodes
     if ((modes & (1u << SR_MODE_BVH)) && s->argb.size() >= (1u << 26))
         return fail(SR_ERR_UNSUPPORTED, "the library's BVH holds at most 2^26 - 1 triangles");
     if (modes & (1u << SR_MODE_REF_TREE)) {
@@ -772,7 +772,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         s->bvh_dirty = false;
         s->cam_valid = false;
     } else if (modes & (1u << SR_MODE_BVH)) {
-        sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(7, s->dbg[SR_DBG_BVH_LEAF]) : 4);
+        sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(15, s->dbg[SR_DBG_BVH_LEAF]) : 7);
         if (s->bvh.depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
         s->bvh_on_device = false;
         s->bvh_dirty = true;

@@ -247,7 +247,7 @@ bool build_ref_tree(const std::vector<double>& v9, const double bmin[3], const d
 }
 
 // ------------------------------------------------------------------------------------------------
-// own BVH: binned SAH over centroids, <= 4 triangles per leaf, children's boxes stored in the parent
+// own BVH: binned SAH over centroids, <= 7 triangles per leaf, children's boxes stored in the parent
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct Aabb {
@@ -269,7 +269,7 @@ struct BvhBuilder {
     Bvh& out;
     const RootBox& root;
     double pad;
-    int kLeafMax = 4;                // triangles per leaf (sr_debug_set(SR_DBG_BVH_LEAF) = 1..7 overrides: experiment hook)
+    int kLeafMax = 7;                // triangles per leaf (measured on the packet walks: 2: 22.7 ms, 4: 20.8, 7: 19.5, 10: 19.9, 15: 20.0) (sr_debug_set(SR_DBG_BVH_LEAF) = 1..7 overrides: experiment hook)
 
     float down(double v) const { float f = (float)v; if ((double)f > v) f = std::nextafterf(f, -INFINITY); return f; }
     float up(double v) const { float f = (float)v; if ((double)f < v) f = std::nextafterf(f, INFINITY); return f; }
@@ -349,7 +349,7 @@ void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int
     double ext = 0;
     for (int a = 0; a < 3; ++a) ext = std::max(ext, root.max[a] - root.min[a]);
     BvhBuilder bb{{}, {}, out, root, std::ldexp(ext > 0 ? ext : 1.0, -16)};
-    bb.kLeafMax = std::min(7, std::max(1, leaf_max));
+    bb.kLeafMax = std::min(15, std::max(1, leaf_max));
     bb.tb.resize(n);
     bb.cen.resize(n * 3);
     out.order.resize(n);

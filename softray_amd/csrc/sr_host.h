@@ -55,7 +55,7 @@ struct Bvh {
     int32_t depth = 0;
     bool built = false;
 };
-void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int leaf_max = 4);
+void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int leaf_max = 7);
 
 // ---- Instance / Renderer helpers ----
 void instance_matrices(const double position[3], double yaw, double pitch, double roll,

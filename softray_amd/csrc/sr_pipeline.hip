@@ -499,7 +499,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         int32_t ni = 0;
         float nu = 1.0f;               // upper bound of u (distance from the surface end) inside the current subtree
         // while-while: walk inner nodes until this lane owns a pending leaf, then run the (per-triangle) slab filters
-        int32_t leafA = -1, leafB = -1;            // pending leaves: first record | count << 28
+        int32_t leafA = -1, leafB = -1;            // pending leaves: first record | count << kLeafShift
         float laA = 0, lbA = 0, laB = 0, lbB = 0;  // their u-intervals
         for (;;) {
             while (ni >= 0 && leafA < 0) {
@@ -516,10 +516,10 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                 const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
                 if (l0 && l1) {
                     const bool first0 = a0 <= a1;
-                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << 28); laA = first0 ? a0 : a1; lbA = first0 ? b0 : b1;
-                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << 28); laB = first0 ? a1 : a0; lbB = first0 ? b1 : b0;
-                } else if (l0) { leafA = n.c0 | (n.n0 << 28); laA = a0; lbA = b0; }
-                else if (l1) { leafA = n.c1 | (n.n1 << 28); laA = a1; lbA = b1; }
+                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << kLeafShift); laA = first0 ? a0 : a1; lbA = first0 ? b0 : b1;
+                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << kLeafShift); laB = first0 ? a1 : a0; lbB = first0 ? b1 : b0;
+                } else if (l0) { leafA = n.c0 | (n.n0 << kLeafShift); laA = a0; lbA = b0; }
+                else if (l1) { leafA = n.c1 | (n.n1 << kLeafShift); laA = a1; lbA = b1; }
                 const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
                 if (i0 && i1) {
                     const bool first0 = a0 <= a1;                          // the child nearest to the surface point first
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
             }
             if (leafA < 0) break;
             while (leafA >= 0 && !truncated && !umbra) {
-                const int first = leafA & 0x0fffffff, cnt = (leafA >> 28) & 7;
+                const int first = leafA & kLeafMask, cnt = (leafA >> kLeafShift) & 15;
                 leafA = leafB; laA = laB; lbA = lbB;
                 leafB = -1;
                 leaves++;
@@ -1437,10 +1437,10 @@ __global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc,
                 const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
                 if (l0 && l1) {                                   // nearer leaf first
                     const bool first0 = t0 <= t1;
-                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << 28);
-                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << 28);
-                } else if (l0) leafA = n.c0 | (n.n0 << 28);
-                else if (l1) leafA = n.c1 | (n.n1 << 28);
+                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << kLeafShift);
+                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << kLeafShift);
+                } else if (l0) leafA = n.c0 | (n.n0 << kLeafShift);
+                else if (l1) leafA = n.c1 | (n.n1 << kLeafShift);
                 const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
                 if (i0 && i1) {
                     const bool first0 = t0 <= t1;
@@ -1452,7 +1452,7 @@ __global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc,
             }
             bool blocked = false;
             while (leafA >= 0 && !blocked) {
-                const int32_t first = leafA & 0x0fffffff, cn = (leafA >> 28) & 7;
+                const int32_t first = leafA & kLeafMask, cn = (leafA >> kLeafShift) & 15;
                 leafA = leafB;
                 leafB = -1;
                 sec.leaves++;
@@ -1658,10 +1658,10 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
                 const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
                 if (l0 && l1) {                                   // nearer leaf first
                     const bool first0 = t0 <= t1;
-                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << 28);
-                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << 28);
-                } else if (l0) leafA = n.c0 | (n.n0 << 28);
-                else if (l1) leafA = n.c1 | (n.n1 << 28);
+                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << kLeafShift);
+                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << kLeafShift);
+                } else if (l0) leafA = n.c0 | (n.n0 << kLeafShift);
+                else if (l1) leafA = n.c1 | (n.n1 << kLeafShift);
                 const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
                 if (i0 && i1) {
                     const bool first0 = t0 <= t1;
@@ -1672,7 +1672,7 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
                 else ni = (sp > 0) ? st.get(--sp) : -1;
             }
             while (leafA >= 0) {
-                const int32_t first = leafA & 0x0fffffff, cn = (leafA >> 28) & 7;
+                const int32_t first = leafA & kLeafMask, cn = (leafA >> kLeafShift) & 15;
                 leafA = leafB;
                 leafB = -1;
                 sec.leaves++;

@@ -152,6 +152,10 @@ __device__ __forceinline__ bool clip_segment(const RootBox& rb, D3& start, D3& e
     return true;
 }
 
+// a lane's pending leaf in one word: first record | count << kLeafShift (<= 15 triangles per leaf, < 2^27 records)
+constexpr int kLeafShift = 27;
+constexpr int32_t kLeafMask = (1 << kLeafShift) - 1;
+
 // Per-lane traversal stack in LDS, laid out [level][thread]: consecutive lanes hit consecutive banks.
 struct Stack {
     int32_t* base;      // &lds[threadIdx]
@@ -294,7 +298,7 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
     // once per node step for the few lanes that happen to be at a leaf.
     int sp = 0;
     int32_t ni = 0;                  // next inner node, -1: walk finished
-    int32_t leafA = -1, leafB = -1;  // pending leaves: first record | count << 28
+    int32_t leafA = -1, leafB = -1;  // pending leaves: first record | count << kLeafShift
     for (;;) {
         while (ni >= 0 && leafA < 0) {
             const BvhNode n = sc.bnodes[ni];
@@ -306,10 +310,10 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
             const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
             if (l0 && l1) {                                   // nearer leaf first
                 const bool first0 = t0 <= t1;
-                leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << 28);
-                leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << 28);
-            } else if (l0) leafA = n.c0 | (n.n0 << 28);
-            else if (l1) leafA = n.c1 | (n.n1 << 28);
+                leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << kLeafShift);
+                leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << kLeafShift);
+            } else if (l0) leafA = n.c0 | (n.n0 << kLeafShift);
+            else if (l1) leafA = n.c1 | (n.n1 << kLeafShift);
             const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
             if (i0 && i1) {
                 const bool first0 = t0 <= t1;
@@ -321,7 +325,7 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
         }
         if (leafA < 0) break;
         while (leafA >= 0) {
-            const int32_t first = leafA & 0x0fffffff, cn = (leafA >> 28) & 7;
+            const int32_t first = leafA & kLeafMask, cn = (leafA >> kLeafShift) & 15;
             leafA = leafB;
             leafB = -1;
             c.leaves++;
