@@ -308,6 +308,8 @@ enum {
     SR_DBG_PER_LANE_SHAFT = 9,   /* > 0: first shaft round with private per-lane walks (k_shaft) instead of the wave-cooperative
                                     packet walk (k_shaft_pkt): same lists up to order, same pixels; cross-check                */
     SR_DBG_PER_LANE_PRIMARY = 10, /* > 0: primary rays with private per-lane walks instead of the packet walk + camera-cone filter */
+    SR_DBG_ROUND2_NODES   = 11,  /* node budget of a private shaft walk of the later rounds (0 = unlimited): walks that exceed it hand
+                                    their undecided samples to the exact fallback */
     SR_DBG_COUNT          = 16
 };
 int  sr_debug_set(sr_scene*, int32_t key, int64_t value);

@@ -11,9 +11,12 @@ v9, argb = sa.make_random_triangles(args.tris, 12345, space=1.0 - args.extent, e
 g = sa.GpuScene(0)
 g.set_triangles(v9, argb, np.array([-0.5] * 3), np.array([0.5] * 3))
 g.build((sa.MODE_BVH,))
+for kv in sys.argv[1:]:                                  # sr_debug_set hooks: key=value
+    k, v = kv.split("=")
+    g.debug_set(int(k), int(v))
 out = {}
 STRIP = int(os.environ.get("STRIP_ROWS", "16"))
-for n in (1, 2, 4, 8):
+for n in (1, 8):
     times = []
     for k in range(n):
         f = bench.make_frame(args, (STRIP, n, k) if n > 1 else None)
@@ -27,10 +30,13 @@ for n in (1, 2, 4, 8):
             g.render_device(f, buf.data_ptr(), s.cuda_stream)
         torch.cuda.synchronize()
         times.append((time.perf_counter() - t) / 3 * 1e3)
-        if k == 0:
+        if k == 0:                                       # kernel times of one rank's share, as ONE pipeline (no overlapping kernels)
+            g.debug_set(sa._lib.DBG_KERNEL_TIMING, 1)
             g.reset_kernel_times()
+            f.flags |= sa._lib.F_NO_SPLIT
             g.render_device(f, buf.data_ptr(), s.cuda_stream)
             torch.cuda.synchronize()
             kt = {kk: round(v[0], 2) for kk, v in g.kernel_times().items()}
+            g.debug_set(sa._lib.DBG_KERNEL_TIMING, -1)
     out[n] = {"max_ms": max(times), "min_ms": min(times), "speedup_bound": out[1]["max_ms"] / max(times) if n > 1 else 1.0, "kernels_rank0_ms": kt}
 print(json.dumps(out))

@@ -34,7 +34,7 @@ SYMBOLS = [
 ]
 # sr_debug_set keys (include/softray.h)
 (DBG_BAND_SAMPLES, DBG_ROUND_CAP0, DBG_ROUND_CAP1, DBG_SPLIT, DBG_FB_RAY_CAP, DBG_BVH_LEAF, DBG_KERNEL_SWITCH,
- DBG_KERNEL_TIMING, DBG_EXACT_SHADOW_TESTS, DBG_PER_LANE_SHAFT, DBG_PER_LANE_PRIMARY) = range(11)
+ DBG_KERNEL_TIMING, DBG_EXACT_SHADOW_TESTS, DBG_PER_LANE_SHAFT, DBG_PER_LANE_PRIMARY, DBG_ROUND2_NODES) = range(12)
 
 
 class Prim(C.Structure):

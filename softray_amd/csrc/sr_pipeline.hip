@@ -455,7 +455,7 @@ __device__ __forceinline__ int shaft_touches(const TriSlab s, const ShaftRay& sr
 template <bool STATS>
 __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
                                                const unsigned int* __restrict__ hit_count, unsigned int count_cap,
-                                               const unsigned int* __restrict__ index_list, int skip, int cap,
+                                               const unsigned int* __restrict__ index_list, int node_budget, int cap,
                                                unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
                                                uint32_t* __restrict__ samples, unsigned int* __restrict__ work_count,
                                                unsigned int* __restrict__ work_list, unsigned long long* stats, unsigned int* dbg) {
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         const int nbits = sc.bnode_bits, qmax = (1 << (31 - nbits)) - 1;   // stack word = node | quantised u bound
         const float qinv = 1.0f / (float)qmax * 1.000001f;
         int32_t* out = cand + (size_t)slot_i * cap;
-        int count = -skip;             // candidates with ordinal < skip were handled by an earlier round
+        int count = 0;
         bool truncated = false, umbra = false;
         int sp = 0;
         int32_t ni = 0;
@@ -505,6 +505,10 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
             while (ni >= 0 && leafA < 0) {
                 const BvhNode n = sc.bnodes[ni];
                 nodes++;
+                // a private walk is a chain of dependent fetches and the kernel lasts as long as its longest one: with a budget
+                // (sr_debug_set, default none) a walk that has not filled its list within node_budget nodes gives up ("truncated":
+                // its undecided samples go to the exact fallback)
+                if (node_budget > 0 && nodes > (uint32_t)node_budget) { truncated = true; break; }
                 const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
                 const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
                 float a0, b0, a1, b1;      // child u-intervals [a, b]
@@ -1029,6 +1033,8 @@ __global__ __launch_bounds__(256) void k_shadow_test(DevScene sc, FrameConst fc,
 // --------------------------------------------------------------------------------------------------
 constexpr float kU24 = 5.9604645e-8f;    // 2^-24
 constexpr int kClsCand = 32;             // candidates staged per chunk (5 float4 each): one bit each in a lane's "uncertain" masks
+// LDS of one wave of k_shadow_cls, in float4 units: records + pair-transposed records + record indices + tail tables
+constexpr int kClsWaveF4 = kClsCand * 5 + (kClsCand / 2) * 10 + kClsCand / 4 + 16 + 32 + 32 + 1;
 
 struct ClsFrame {                         // per-frame fp32 constants of the classification
     float cx, cy, cz, hbx, hby, hbz, s0, a0, R;
@@ -1058,12 +1064,19 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                                                     uint32_t* __restrict__ samples, unsigned long long* stats) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    float4* wc = reinterpret_cast<float4*>(lds_pipe) + (size_t)wave * (kClsCand * 5 + kClsCand / 4);
-    int32_t* wrecidx = reinterpret_cast<int32_t*>(wc + kClsCand * 5);    // record position of every staged candidate
+    float4* wc = reinterpret_cast<float4*>(lds_pipe) + (size_t)wave * kClsWaveF4;   // per-candidate records (owner layout)
+    float4* wpair = wc + kClsCand * 5;                                      // the same records transposed in pairs (tail layout)
+    int32_t* wrecidx = reinterpret_cast<int32_t*>(wpair + (kClsCand / 2) * 10);   // record position of every staged candidate
+    uint32_t* wids = reinterpret_cast<uint32_t*>(wrecidx + kClsCand);       // [64] sample of every tail slot
+    float* wum = reinterpret_cast<float*>(wids + 64);                       // [128] umax of every sample of the current hit point
+    uint32_t* wunc = reinterpret_cast<uint32_t*>(wum + 128);                // [128] undecided candidates of every sample (tail)
+    uint32_t* wdead = wunc + 128;                                           // [4] samples the tail found blocked
     const int S = fc.shadow_samples;
+    float* offtab = reinterpret_cast<float*>(reinterpret_cast<float4*>(lds_pipe) + 4 * kClsWaveF4);   // [128][3] area-light offsets, fp32
     // ShadowMethod.IntersectRay's byte for every possible rayEscapeCount (:113-119 / the static cache's :80), made once per
     // workgroup with the reference's FP64 expressions instead of one FP64 division per hit point
-    uint32_t* light_byte = reinterpret_cast<uint32_t*>(reinterpret_cast<float4*>(lds_pipe) + 4 * (kClsCand * 5 + kClsCand / 4));
+    uint32_t* light_byte = reinterpret_cast<uint32_t*>(offtab + 128 * 3);
+    for (int e = tid; e < 128 * 3; e += 256) offtab[e] = e < 3 * S ? (float)offsets[e] : 0.0f;
     for (int e = tid; e <= S; e += 256) {
         const double frac = (double)e / (double)S;
         uint32_t v;
@@ -1175,6 +1188,7 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
             UM = (f2){ok0 ? ut.x : -1.0f, ok1 ? ut.y : -1.0f};
         }
         const float hbm = cf.a0 + a1;
+        wum[lane] = UM.x; wum[lane + 64] = UM.y;                          // (the tail layout fetches a sample's umax by its index)
         bool have = __any(alive[0] || alive[1]);
         for (int base = 0; base < ntri && have; base += kClsCand) {
             const int nc = min(kClsCand, ntri - base);
@@ -1210,7 +1224,21 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                 // .z: margin of "outside an edge" (always reached when E' is definitely in front of the plane)
                 w[4] = make_float4(G0, G0 <= -cf.a0 ? mc : 1e30f, G0 >= cf.a0 ? -1e30f : mc, 0.0f);
                 wrecidx[lane] = ent;
+                // the same 20 floats once more, interleaved with the neighbour candidate's (pair p = lane / 2: float 2 f + (lane & 1)),
+                // so that the tail layout reads both candidates of a pair as packed operands
+                float* pr = reinterpret_cast<float*>(wpair + (lane >> 1) * 10) + (lane & 1);
+                const float rec20[20] = {slab.n[0], slab.n[1], slab.n[2], N.y, W[0].x, W[0].y, W[0].z, W[0].w, W[1].x, W[1].y, W[1].z, W[1].w,
+                                         W[2].x, W[2].y, W[2].z, W[2].w, G0, G0 <= -cf.a0 ? mc : 1e30f, G0 >= cf.a0 ? -1e30f : mc, 0.0f};
+#pragma unroll
+                for (int e = 0; e < 20; ++e) pr[2 * e] = rec20[e];
+            } else if (lane == nc && (nc & 1)) {
+                // odd count: the last pair's second candidate is a null record -- in front of the surface point, "decided: miss" for every sample
+                float* pr = reinterpret_cast<float*>(wpair + (lane >> 1) * 10) + 1;
+#pragma unroll
+                for (int e = 0; e < 20; ++e) pr[2 * e] = e == 3 ? 1.0f : (e == 16 ? 1.0f : (e == 17 ? 1e30f : (e == 18 ? -1e30f : 0.0f)));
             }
+            wunc[lane] = 0u; wunc[lane + 64] = 0u;
+            if (lane < 4) wdead[lane] = 0u;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             n_recs += (uint32_t)nc;
@@ -1219,7 +1247,11 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
             //      sample (dead samples keep running through the arithmetic: nothing they produce is looked at) ----
             uint32_t unc[kPacketSlots] = {0u, 0u};
             float bsum[kPacketSlots] = {-1.0f, -1.0f};
-            for (int k = 0; k < nc && have; ++k) {
+            int k = 0;
+            unsigned long long am0 = 0ull, am1 = 0ull;                    // (wave-uniform) samples still undecided
+            int na = 128;
+            for (; k < nc && have; ++k) {
+                if (!(k & 1) && na <= 64) break;                          // few samples left: the tail layout takes the rest of the chunk
                 const float4 A = wc[k * 5], B1 = wc[k * 5 + 1], B2 = wc[k * 5 + 2], B3 = wc[k * 5 + 3], F = wc[k * 5 + 4];
                 // packed over the lane's two samples (.x = sample lane, .y = sample lane + 64)
                 const f2 g1 = pk_fma(splat(A.x), OX, pk_fma(splat(A.y), OY, pk_fma(splat(A.z), OZ, splat(A.w))));
@@ -1239,6 +1271,86 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                     unc[q] |= tall > 0.0f ? 0u : (1u << k);
                 }
                 if (STATS) n_cls += (alive[0] && !(bsum[0] > 0.0f) ? 1u : 0u) + (alive[1] && !(bsum[1] > 0.0f) ? 1u : 0u);
+                am0 = __ballot(alive[0] && !(bsum[0] > 0.0f)); am1 = __ballot(alive[1] && !(bsum[1] > 0.0f));
+                na = (int)__popcll(am0) + (int)__popcll(am1);
+                have = na != 0;
+            }
+            if (k == 0 && have) {                                         // (entered with few samples: later rounds, later chunks)
+                am0 = __ballot(alive[0]); am1 = __ballot(alive[1]);
+                na = (int)__popcll(am0) + (int)__popcll(am1);
+            }
+            // ---- tail layout: the na <= 64 undecided samples are compacted into sample slots; a lane is one (slot, candidate PAIR),
+            //      so a pass tests 2 * 64 / W candidates against every remaining sample (W = 8, 16, 32 or 64 slots).  Same arithmetic,
+            //      packed over the two candidates of a pair instead of over two samples ----
+            if (have && k < nc && na <= 64) {
+                const bool mine0 = alive[0] && !(bsum[0] > 0.0f), mine1 = alive[1] && !(bsum[1] > 0.0f);
+                if (mine0) wids[__popcll(am0 & lanemask_lt())] = (uint32_t)lane;
+                if (mine1) wids[__popcll(am0) + __popcll(am1 & lanemask_lt())] = (uint32_t)lane + 64u;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                unsigned long long sm = na >= 64 ? ~0ull : ((1ull << na) - 1ull);   // (wave-uniform) live slots
+                for (;;) {
+                    const int nslot = (int)__popcll(sm);                  // == highest live slot + 1 right after a compaction
+                    const int sh = nslot <= 8 ? 3 : (nslot <= 16 ? 4 : (nslot <= 32 ? 5 : 6));
+                    const int W = 1 << sh, a = lane & (W - 1), j = lane >> sh, groups = 64 >> sh;
+                    const bool slot_live = ((sm >> a) & 1ull) != 0ull;
+                    const uint32_t sid = slot_live ? wids[a] : 0u;
+                    const float ox = offtab[3 * sid], oy = offtab[3 * sid + 1], oz = offtab[3 * sid + 2], um = wum[sid];
+                    const f2 sox = splat(ox), soy = splat(oy), soz = splat(oz);
+                    unsigned long long dead = 0ull;
+                    bool recompact = false;
+                    while (k < nc && sm != 0ull) {
+                        const int p = (k >> 1) + j;                       // this lane's candidate pair (2 p, 2 p + 1)
+                        const bool act = slot_live && ((sm >> a) & 1ull) != 0ull && 2 * p < nc;
+                        const float4* pq = wpair + (act ? p : 0) * 10;
+                        const float4 q0 = pq[0], q1 = pq[1], q2 = pq[2], q3 = pq[3], q4 = pq[4], q5 = pq[5], q6 = pq[6], q7 = pq[7], q8 = pq[8], q9 = pq[9];
+                        const f2 g1 = pk_fma((f2){q0.x, q0.y}, sox, pk_fma((f2){q0.z, q0.w}, soy, pk_fma((f2){q1.x, q1.y}, soz, (f2){q1.z, q1.w})));
+                        const f2 c1 = pk_fma((f2){q2.x, q2.y}, sox, pk_fma((f2){q2.z, q2.w}, soy, pk_fma((f2){q3.x, q3.y}, soz, (f2){q3.z, q3.w})));
+                        const f2 c2 = pk_fma((f2){q4.x, q4.y}, sox, pk_fma((f2){q4.z, q4.w}, soy, pk_fma((f2){q5.x, q5.y}, soz, (f2){q5.z, q5.w})));
+                        const f2 c3 = pk_fma((f2){q6.x, q6.y}, sox, pk_fma((f2){q6.z, q6.w}, soy, pk_fma((f2){q7.x, q7.y}, soz, (f2){q7.z, q7.w})));
+                        const f2 hb = pk_fma(splat(um), g1, (f2){q8.x, q8.y});
+                        const f2 cmin = {fminf(fminf(c1.x, c2.x), c3.x), fminf(fminf(c1.y, c2.y), c3.y)};
+                        const f2 s3 = g1 - splat(glo), s1 = cmin - (f2){q8.z, q8.w}, s4 = hb - splat(hbm);
+                        const f2 tm0 = -(f2){q9.x, q9.y} - cmin, bfv = splat(-glo) - g1;
+                        const float tb0 = fminf(fminf(s1.x, s3.x), s4.x), tb1 = fminf(fminf(s1.y, s3.y), s4.y);
+                        const float ta0 = fmaxf(fmaxf(fminf(tm0.x, s3.x), bfv.x), tb0), ta1 = fmaxf(fmaxf(fminf(tm0.y, s3.y), bfv.y), tb1);
+                        const bool blk = act && (tb0 > 0.0f || tb1 > 0.0f);
+                        if (act && !blk) {                                // undecided pairs of a sample this pass does not block (rare)
+                            const uint32_t ub = (ta0 > 0.0f ? 0u : (1u << (2 * p))) | (ta1 > 0.0f ? 0u : (2u << (2 * p)));
+                            if (ub) atomicOr(&wunc[sid], ub);
+                        }
+                        if (STATS) n_cls += act ? 2u : 0u;
+                        unsigned long long m = __ballot(blk);
+                        if (sh <= 5) m |= m >> 32;
+                        if (sh <= 4) m |= m >> 16;
+                        if (sh <= 3) m |= m >> 8;
+                        const unsigned long long nb = m & sm;
+                        sm &= ~nb;
+                        dead |= nb;
+                        k += 2 * groups;
+                        if (sh > 3 && sm != 0ull && (int)__popcll(sm) <= (W >> 1) && k < nc) { recompact = true; break; }
+                    }
+                    // the samples this epoch found blocked, for their owner lanes
+                    if (j == 0 && ((dead >> a) & 1ull) != 0ull) atomicOr(&wdead[sid >> 5], 1u << (sid & 31u));
+                    if (!recompact) break;
+                    // pack the surviving slots again: twice the candidates per pass
+                    const bool keep = j == 0 && ((sm >> a) & 1ull) != 0ull;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (keep) wids[__popcll(sm & ((1ull << a) - 1ull))] = sid;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    sm = (1ull << __popcll(sm)) - 1ull;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                // owners take the tail's verdicts: blocked samples, undecided pairs
+#pragma unroll
+                for (int q = 0; q < kPacketSlots; ++q) {
+                    const uint32_t sidq = (uint32_t)lane + 64u * q;
+                    if (((wdead[sidq >> 5] >> (sidq & 31u)) & 1u) != 0u) bsum[q] = 1.0f;
+                    unc[q] |= wunc[sidq];
+                }
                 have = __any((alive[0] && !(bsum[0] > 0.0f)) || (alive[1] && !(bsum[1] > 0.0f)));
             }
 #pragma unroll
@@ -1969,8 +2081,8 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                 size_t lds = (size_t)levels * 256 * 4;
                 unsigned int* wc = first ? work0 : nullptr;
                 unsigned int* wl = first ? L.round_list[0] : nullptr;
-                if (L.stats) hipLaunchKernelGGL((k_shaft<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, 0, cap, L.round_cand_count[round], L.round_cand[round], samples, wc, wl, L.stats, L.counters);
-                else hipLaunchKernelGGL((k_shaft<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, 0, cap, L.round_cand_count[round], L.round_cand[round], samples, wc, wl, L.stats, L.counters);
+                if (L.stats) hipLaunchKernelGGL((k_shaft<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, first ? 0 : L.round2_node_budget, cap, L.round_cand_count[round], L.round_cand[round], samples, wc, wl, L.stats, L.counters);
+                else hipLaunchKernelGGL((k_shaft<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, first ? 0 : L.round2_node_budget, cap, L.round_cand_count[round], L.round_cand[round], samples, wc, wl, L.stats, L.counters);
             }
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
@@ -1992,7 +2104,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
             const unsigned int* t_list = first ? L.round_list[0] : ilist;
             if (!L.exact_shadow_tests) {
                 // default: fp32 classification, FP64 only for the pairs it cannot decide
-                const size_t lds_c = 4 * ((size_t)kClsCand * 5 + kClsCand / 4) * sizeof(float4) + (64 * kPacketSlots + 1) * sizeof(uint32_t);
+                const size_t lds_c = 4 * (size_t)kClsWaveF4 * sizeof(float4) + 128 * 3 * sizeof(float) + (64 * kPacketSlots + 1) * sizeof(uint32_t);
                 if (L.stats) hipLaunchKernelGGL((k_shadow_cls<EXTRA, true>), dim3(blocks), dim3(256), lds_c, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
                 else hipLaunchKernelGGL((k_shadow_cls<EXTRA, false>), dim3(blocks), dim3(256), lds_c, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
             } else if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
