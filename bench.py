@@ -385,18 +385,17 @@ def main():
         out["readback_equals_blocking_render"] = bool(np.array_equal(last_host_frame, host_px))
         # algorithmic bytes per LAUNCH (one pipeline = one launch per frame of every kernel) = what the launch must move at
         # least once:
-        #   k_primary (packet walk)  4 B pixel per ray + 64 B per node a lane's ray needed + 64 B per camera-cone record it
-        #                            consulted (lane counts: an upper bound of the wave-level traffic) + 64 B queue record per hit
+        #   k_primary (packet walk)  4 B pixel per ray + per WAVE 64 B/node + 64 B/camera-cone record + 128 B/FP64 record fetched
+        #                            + 64 B queue record per hit
         #   k_shaft (packet walk)    per hit point 64 B queue record + 4 B count; per WAVE 64 B/node + 64 B/TriSlab; 4 B per list entry
         #   k_shadow (k_shadow_cls)  per hit point 64 B + 4 B + 8 B pixel RMW; per candidate 4 B list entry + 64 B TriSlab
         pkt_nodes, pkt_slabs = rs[6] - rs[14], rs[10] - rs[15]
         algo = {
-            "k_primary": S_PIX * npix + rs[2] * S_NODE + rs[1] * S_SLAB + 64.0 * rs[11],
+            "k_primary": S_PIX * npix + rs[2] * S_NODE + rs[1] * S_SLAB + rs[3] * S_TRI + 64.0 * rs[11],
             "k_shaft": rs[11] * (64.0 + 4.0) + pkt_nodes * S_NODE + pkt_slabs * S_SLAB + rs[8] * 4.0,
             "k_shaft_round2": rs[14] * S_NODE + rs[15] * S_SLAB,
             "k_shadow": rs[9] * (64.0 + 4.0 + 8.0) + rs[8] * ((S_TRI if args.exact_shadow_tests else S_SLAB) + 4.0),
         }
-        per_ray_touch = S_PIX * npix + (rs[2] + rs[6]) * S_NODE + (rs[1] + rs[5]) * S_TRI     # SURVEY 8d's per-lane figure
         dom = max(kt.items(), key=lambda kv: kv[1][0]) if kt else ("none", (float("nan"), 0))
         dom_name, dom_ms = dom[0], dom[1][0]
         algo_bytes = algo.get(dom_name, float("nan"))
@@ -414,7 +413,6 @@ def main():
                          "kernel": dom_name, "kernel_ms_per_launch": dom_ms, "launches_timed": dom[1][1], "algorithmic_bytes_per_launch": algo_bytes,
                          "all_kernels_ms_per_launch": {k: v[0] for k, v in kt.items()},
                          "all_kernels_algorithmic_GBs": {k: algo[k] / (v[0] * 1e-3) / 1e9 for k, v in kt.items() if k in algo and v[0] > 0},
-                         "per_ray_touch_bytes_per_frame": per_ray_touch,
                          "note": "achieved = algorithmic bytes of ONE launch of the dominant kernel / its average launch duration (HIP event pairs on the "
                                  "launch stream, frames rendered as one pipeline so that no two kernels share the GPU).  The scene (128 MB records + 21 MB BVH + "
                                  "2 x 64 MB fp32 records) is cache resident; the kernels are bound by instruction issue (see roofline_issue), not by HBM"},

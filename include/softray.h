@@ -255,7 +255,9 @@ void sr_reset_kernel_times(sr_scene*);
 int  sr_kernel_times(sr_scene*, sr_kernel_time* out, int32_t cap);
 
 /* Ray statistics of the last sr_render(..., stats != NULL): [0..3] primary rays {rays, triangle/primitive tests, nodes
- * visited, leaf nodes visited}; [4..7] the same for secondary (shadow) rays -- on the shaft path [6],[7] are the shaft
+ * visited, leaf nodes visited} -- the reference's notions in SR_MODE_REF_TREE / SR_MODE_BRUTE; on the own BVH the primary walk is one
+ * packet walk per 8x8-pixel tile and [1..3] count what a WAVE fetched: [1] 64-byte camera-cone records consulted, [2] 64-byte
+ * nodes, [3] 128-byte FP64 triangle records; [4..7] the same for secondary (shadow) rays -- on the shaft path [6],[7] are the shaft
  * walks' nodes / leaves; [8] triangle records staged through LDS by k_shadow_test, [9] hit points it processed,
  * [10] fp32 slab records read by k_shaft, [11] hit points it walked, [12] (sample, triangle) pairs k_shadow_test classified
  * in fp32, [13] pairs it had to decide with the exact FP64 test, [14] / [15] the part of [6] / [10] that came from private per-lane

@@ -4,5 +4,5 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/lanes_${1:-r01}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/pmc -o pmc -- python3 $REPO/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split > $OUT/bench.json 2> $OUT/err.txt
+rocprofv3 --kernel-trace --pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $OUT/pmc -o pmc -- python3 $REPO/bench.py --steps 2 --warmup 1 --prelude-s 0 --no-cpu-baseline --no-split > $OUT/bench.json 2> $OUT/err.txt
 tail -2 $OUT/err.txt

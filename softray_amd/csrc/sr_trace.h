@@ -400,7 +400,9 @@ __device__ bool bvh_packet_nearest(const DevScene& sc, int32_t* wnode, bool live
     if (__ballot(act) != 0ull) {
         for (;;) {
             const BvhNode n = sc.bnodes[ni];                           // wave-uniform address: scalar loads
-            if (act) c.nodes++;
+            // counters of the packet walk are per WAVE (what the wave fetched), kept by its first participating lane:
+            // nodes = 64-byte nodes, geom = 64-byte camera-cone records consulted, leaves = 128-byte FP64 records fetched
+            if (act && (__ffsll((long long)__ballot(act)) - 1) == (int)(threadIdx.x & 63u)) c.nodes++;
             float t0, x0, t1, x1;
             node_slabs(n, I01, I20, I12, B0, B1, B2, t0, x0, t1, x1);
             const bool h0 = act && n.n0 >= 0 && t0 <= x0 && x0 >= 0.0f && t0 <= tlim;
@@ -412,16 +414,17 @@ __device__ bool bvh_packet_nearest(const DevScene& sc, int32_t* wnode, bool live
                 const int cn = c0 ? n.n0 : n.n1, cc = c0 ? n.c0 : n.c1;
                 const bool hc = (c0 ? h0 : h1) && (c0 ? t0 : t1) <= tlim;       // tlim may have shrunk in the other leaf
                 if (cn > 0 && __ballot(hc) != 0ull) {
-                    if (hc) c.leaves++;
+                    const bool hc_first = hc && (__ffsll((long long)__ballot(hc)) - 1) == (int)(threadIdx.x & 63u);
                     for (int k = cc; k < cc + cn; ++k) {
                         bool cand = hc;
                         if (FILTER) {
                             const CamCone cm = sc.bcam[k];                       // scalar load
                             cand = hc && !cone_rejects(cm, dxx, dyy, dzz, dl);
                         }
-                        if (hc) c.geom++;
+                        if (hc_first) c.geom++;
                         if (__ballot(cand) != 0ull) {
                             const Rec128* r = &sc.btris[k];                       // wave-uniform address
+                            if (cand && (__ffsll((long long)__ballot(cand)) - 1) == (int)(threadIdx.x & 63u)) c.leaves++;
                             if (cand) {
                                 double tt; D3 pos;
                                 if (tri_hit(r->p, s, d, tt, pos) && inside(sc.root.lo, sc.root.hi, pos)) {
