@@ -605,8 +605,9 @@ __global__ __launch_bounds__(256) void k_shaft_pkt(DevScene sc, FrameConst fc, c
                                                    unsigned int* __restrict__ work_list, unsigned long long* stats) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int32_t* wnode = reinterpret_cast<int32_t*>(lds_pipe) + (size_t)wave * ((size_t)levels * 65);   // [levels] stacked node
-    float* wbound = reinterpret_cast<float*>(wnode + levels) + lane;                               // [levels][64] per-lane u bound
+    int32_t* wnode = reinterpret_cast<int32_t*>(lds_pipe) + (size_t)wave * ((size_t)levels * 33);   // [levels] stacked node
+    // [levels][64] per-lane u bound, 16 bits: 0 = the lane's shaft misses the subtree, else 1 + the bound in 1/65534 rounded UP
+    uint16_t* wbound = reinterpret_cast<uint16_t*>(wnode + levels) + lane;
     const unsigned int total = *hit_count;
     const unsigned int slot_i = blockIdx.x * 256u + (unsigned)tid;
     HitRec rec;
@@ -641,7 +642,8 @@ __global__ __launch_bounds__(256) void k_shaft_pkt(DevScene sc, FrameConst fc, c
             bool found = false;
             while (sp > 0) {
                 --sp;
-                const float bu = wbound[sp * 64];
+                const uint32_t qb = wbound[sp * 64];
+                const float bu = qb ? (float)(qb - 1u) * (1.0f / 65534.0f) * 1.000001f : -1.0f;
                 if (__ballot(!done && bu >= 0.0f) != 0ull) { ni = __builtin_amdgcn_readfirstlane(wnode[sp]); nu = bu; found = true; break; }
             }
             if (!found) break;
@@ -685,7 +687,10 @@ __global__ __launch_bounds__(256) void k_shaft_pkt(DevScene sc, FrameConst fc, c
         if (any0 && any1) {
             const int32_t far_node = first0 ? n.c1 : n.c0;
             wnode[sp] = far_node;
-            wbound[sp * 64] = first0 ? (w1 ? b1 : -1.0f) : (w0 ? b0 : -1.0f);
+            {
+                const float fb = first0 ? (w1 ? b1 : -1.0f) : (w0 ? b0 : -1.0f);
+                wbound[sp * 64] = fb < 0.0f ? (uint16_t)0 : (uint16_t)min(65535, (int)(fminf(fb, 1.0f) * 65534.0f) + 2);
+            }
             sp++;
             ni = first0 ? n.c0 : n.c1;
             nu = first0 ? (w0 ? b0 : -1.0f) : (w1 ? b1 : -1.0f);
@@ -2071,7 +2076,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
             unsigned blocks = (unsigned)((max_items + 255) / 256);
             if (first && !L.per_lane_shaft) {
                 // round 1: one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
-                size_t lds = (size_t)levels * 65 * 4 * 4;
+                size_t lds = ((size_t)levels * 4 + (size_t)levels * 64 * 2) * 4;
                 if (L.stats) hipLaunchKernelGGL((k_shaft_pkt<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, levels, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
                 else hipLaunchKernelGGL((k_shaft_pkt<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, levels, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
             } else {
