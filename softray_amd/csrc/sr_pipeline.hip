@@ -55,7 +55,7 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
 // PKT (own BVH, all rays of the frame share one origin): the wave walks the tree once (bvh_packet_nearest, sr_trace.h) and
 // consults the frame's camera-cone records before the FP64 triangle test
 template <int MODE, bool EXTRA, bool STATS, bool SUB, bool PKT>
-__global__ __launch_bounds__(256, (SUB || PKT) ? 5 : 6) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
+__global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
                                                  int row_count, uint32_t* __restrict__ samples, HitRec* __restrict__ hits,
                                                  unsigned int* __restrict__ hit_count, uint32_t* __restrict__ bounce_levels,
                                                  uint8_t* __restrict__ bounce_nlev, unsigned long long* stats, int pad_tiles, int levels) {
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
 // here all lanes are at the same node at the same time.
 // --------------------------------------------------------------------------------------------------
 template <bool STATS>
-__global__ __launch_bounds__(256) void k_shaft_pkt(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
+__global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
                                                    const unsigned int* __restrict__ hit_count, int cap, int levels,
                                                    unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
                                                    uint32_t* __restrict__ samples, unsigned int* __restrict__ work_count,
