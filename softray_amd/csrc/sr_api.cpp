@@ -748,14 +748,8 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         const size_t n = s->argb.size();
         DBuf d_slab;
         DBuf& d_v9 = s->d_v9;                                             // uploaded by sync_geometry with the records
-        {
-            std::vector<sr::TriSlab> slabs(n);
-            for (size_t i = 0; i < n; ++i) {
-                const double* p = &s->v9[i * 9];
-                slabs[i] = sr::make_tri_slab({p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}, s->root.centre);
-            }
-            SR_HIP(d_slab.upload(slabs));
-        }
+        SR_HIP(d_slab.reserve(n * sizeof(sr::TriSlab)));
+        SR_HIP(sr::make_slabs_device((const double*)d_v9.p, (int)n, s->root, (sr::TriSlab*)d_slab.p, nullptr));   // (the host loop + upload cost 0.4 s at 10 M)
         SR_HIP(s->d_bnodes.reserve(n * sizeof(sr::BvhNode)));
         SR_HIP(s->d_btris.reserve(n * sizeof(sr::Rec128)));
         SR_HIP(s->d_bslab.reserve(n * sizeof(sr::TriSlab)));

@@ -103,6 +103,9 @@ size_t pipeline_round_state_bytes();
 hipError_t build_bvh_device(const double* d_v9, int n, const RootBox& root, const Rec128* d_tris, const TriSlab* d_slab_in,
                             BvhNode* d_nodes, Rec128* d_btris, TriSlab* d_bslab, int* num_nodes, int* depth, hipStream_t stream);
 
+// fp32 TriSlab records of n triangles (TriangleIndex order) computed on the device from the FP64 vertices (sr_lbvh.hip)
+hipError_t make_slabs_device(const double* d_v9, int n, const RootBox& root, TriSlab* d_out, hipStream_t stream);
+
 // Surface passes (sr_post.hip): PostProcessImage colour functions and AntiAliasImage, Renderer.cs:819-978.
 hipError_t launch_post_process(uint32_t* d_pixels, long long count, int style, uint32_t background, int num_cus, hipStream_t stream);
 hipError_t launch_anti_alias(const uint32_t* d_src, uint32_t* d_dst, int dst_w, int dst_h, int res, hipStream_t stream);

@@ -1,6 +1,6 @@
 // sr_lbvh.hip -- the own BVH built ON THE DEVICE (SURVEY.md 8f "next" row 2: at 1M-10M triangles the host build
 // dominates end-to-end time).  Morton-ordered LBVH (Karras 2012): 63-bit Morton codes of the triangle-box centres ->
-// radix sort (rocPRIM through hipCUB) -> binary radix tree -> bottom-up fp32 boxes -> subtrees of <= 4 triangles are
+// radix sort (rocPRIM through hipCUB) -> binary radix tree -> bottom-up fp32 boxes -> subtrees of <= 7 triangles are
 // collapsed into leaves -> the same 64-byte BvhNode / leaf-ordered record layout the SAH builder produces.
 //
 // Any BVH with conservative boxes gives the same pixels: the traversal (sr_trace.h) decides hits with the reference's
@@ -17,7 +17,7 @@ namespace sr {
 
 namespace {
 
-constexpr int kLeafMax = 4;
+constexpr int kLeafMax = 7;          // like the host SAH builder: the packet walks prefer few, fat leaves
 
 struct FBox { float lo[3], hi[3]; };
 
@@ -172,6 +172,63 @@ struct Tmp {
 }  // namespace
 
 #define LB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return e__; } while (0)
+
+// make_tri_slab (sr_host.cpp) on the device: the fp32 shaft / classification record of every triangle, TriangleIndex order.
+// FP64 arithmetic like the host's; the records are conservative filters, so the two builds need not agree to the last bit
+// (a zero record = "never filtered" is always admissible).
+__global__ void k_make_slabs(const double* __restrict__ v9, int n, double cx, double cy, double cz, TriSlab* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double* p = v9 + (size_t)i * 9;
+    struct V { double x, y, z; };
+    auto sub = [](V a, V b) { return V{a.x - b.x, a.y - b.y, a.z - b.z}; };
+    auto dot = [](V a, V b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+    auto cross = [](V a, V b) { return V{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; };
+    auto scale = [](V a, double s) { return V{a.x * s, a.y * s, a.z * s}; };
+    const V c = {cx, cy, cz};
+    const V v1 = {p[0], p[1], p[2]}, v2 = {p[3], p[4], p[5]}, v3 = {p[6], p[7], p[8]};
+    TriSlab t;
+    t.n[0] = t.n[1] = t.n[2] = t.d = 0.0f;
+    t.m1[0] = t.m1[1] = t.m1[2] = t.c1 = 0.0f; t.m2[0] = t.m2[1] = t.m2[2] = t.c2 = 0.0f; t.m3[0] = t.m3[1] = t.m3[2] = t.c3 = 0.0f;
+    const TriSlab zero = t;
+    bool ok = true;
+    {   // the reference replaces a "zero" normal by (1,0,0) (Triangle.cs:42-43, Vector.cs:140): no planes for such triangles
+        const V n0 = cross(sub(v2, v1), sub(v3, v1));
+        const double e = 1e-10;
+        if (-e < n0.x && n0.x < e && -e < n0.y && n0.y < e && -e < n0.z && n0.z < e) ok = false;
+    }
+    const V a = sub(v1, c), b = sub(v2, c), d3 = sub(v3, c);
+    V nn = cross(sub(b, a), sub(d3, a));
+    const double nl = sqrt(dot(nn, nn));
+    const double e1 = sqrt(dot(sub(b, a), sub(b, a))), e2 = sqrt(dot(sub(d3, b), sub(d3, b))), e3 = sqrt(dot(sub(a, d3), sub(a, d3)));
+    const double emax = fmax(e1, fmax(e2, e3));
+    if (!(nl > 1e-12 * emax * emax) || !(emax > 0) || !isfinite(nl)) ok = false;
+    if (ok) {
+        nn = scale(nn, 1.0 / nl);
+        const V P[3] = {a, b, d3};
+        float* mm[3] = {t.m1, t.m2, t.m3};
+        float* cc[3] = {&t.c1, &t.c2, &t.c3};
+        for (int k = 0; k < 3; ++k) {
+            const V p0 = P[k], p1 = P[(k + 1) % 3], p2 = P[(k + 2) % 3];
+            V m = cross(nn, sub(p1, p0));
+            const double ml = sqrt(dot(m, m));
+            if (!(ml > 0)) { ok = false; break; }
+            m = scale(m, 1.0 / ml);
+            if (dot(m, sub(p2, p0)) < 0) m = scale(m, -1.0);
+            mm[k][0] = (float)m.x; mm[k][1] = (float)m.y; mm[k][2] = (float)m.z;
+            *cc[k] = (float)dot(m, p0);
+        }
+        t.n[0] = (float)nn.x; t.n[1] = (float)nn.y; t.n[2] = (float)nn.z;
+        t.d = (float)dot(nn, a);
+    }
+    out[i] = ok ? t : zero;
+}
+
+hipError_t make_slabs_device(const double* d_v9, int n, const RootBox& root, TriSlab* d_out, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_make_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_v9, n, root.centre[0], root.centre[1], root.centre[2], d_out);
+    return hipGetLastError();
+}
 
 // d_v9: device double[n][9]; d_tris / d_slab_in: records in TriangleIndex order; outputs are caller-allocated:
 // d_nodes (>= n entries), d_btris (n), d_bslab (n).  Returns the node count and depth.
