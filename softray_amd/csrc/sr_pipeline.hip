@@ -1056,7 +1056,9 @@ __device__ __forceinline__ ClsFrame cls_frame(const DevScene& sc, const FrameCon
     return c;
 }
 
-template <bool EXTRA, bool STATS>
+// TAIL: compile the tail layout in.  It pays for the later rounds (few undecided samples from the start); in the first round the
+// 30 registers it costs (162 instead of 128 VGPRs = 3 instead of 4 waves/SIMD) lose more than its shorter candidate loop gains.
+template <bool EXTRA, bool STATS, bool TAIL>
 __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
                                                     const HitRec* __restrict__ hits, const unsigned int* __restrict__ hit_count,
                                                     unsigned int count_cap, const unsigned int* __restrict__ index_list,
@@ -1093,16 +1095,15 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
     const unsigned int total = min(*hit_count, count_cap);
     const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
     const ClsFrame cf = cls_frame(sc, fc);
-    D3 off[kPacketSlots];
     bool valid[kPacketSlots];
-#pragma unroll
-    for (int k = 0; k < kPacketSlots; ++k) {
-        int j = lane + 64 * k;
-        valid[k] = j < S;
-        int jj = valid[k] ? j : 0;
-        off[k] = mk(offsets[3 * jj], offsets[3 * jj + 1], offsets[3 * jj + 2]);
+    f2 OX, OY, OZ;                                                       // fp32 roundings of the lane's two offsets (the FP64 ones are fetched again by the rare exact path)
+    {
+        const int j1 = lane + 64 < S ? lane + 64 : 0, j0 = lane < S ? lane : 0;
+        valid[0] = lane < S; valid[1] = lane + 64 < S;
+        OX = (f2){(float)offsets[3 * j0], (float)offsets[3 * j1]};
+        OY = (f2){(float)offsets[3 * j0 + 1], (float)offsets[3 * j1 + 1]};
+        OZ = (f2){(float)offsets[3 * j0 + 2], (float)offsets[3 * j1 + 2]};
     }
-    const f2 OX = {(float)off[0].x, (float)off[1].x}, OY = {(float)off[0].y, (float)off[1].y}, OZ = {(float)off[0].z, (float)off[1].z};
     uint32_t n_rays = 0, n_items = 0, n_recs = 0, n_cls = 0, n_exact = 0;
     const unsigned int nwaves = gridDim.x * 4u;
     const unsigned int s0 = blockIdx.x * 4u + (unsigned)wave;
@@ -1121,11 +1122,11 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
     if (s0 + nwaves < total) h_nxt = index_list ? index_list[s0 + nwaves] : s0 + nwaves;
     for (unsigned int slot_i = s0; slot_i < total; slot_i += nwaves) {
         const unsigned int h = h_cur;
-        const HitRec rec = rec_cur;
         const unsigned int cc = cc_cur;
         int32_t ent = ent_cur;
         n_items++;
-        const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
+        const D3 E = mk(rec_cur.pos[0], rec_cur.pos[1], rec_cur.pos[2]) + mk(rec_cur.nrm[0], rec_cur.nrm[1], rec_cur.nrm[2]) * 0.001;
+        const uint32_t rec_sample = rec_cur.sample, rec_cell = rec_cur.pad[0];
         const size_t li = lists_by_hit ? (size_t)h : (size_t)slot_i;   // round 0: lists are stored per hit, later rounds per item
         const int ntri = (int)(cc & 0xffffu);
         const bool truncated = (cc & kTruncated) != 0;
@@ -1135,7 +1136,7 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
         TriSlab slab;
         if (lane < ntri) slab = sc.bslab[ent];
         uint32_t shaded = 0;
-        if (lane == 0 && !(fc.flags & 32u)) shaded = samples[rec.sample];
+        if (lane == 0 && !(fc.flags & 32u)) shaded = samples[rec_sample];
         // ---- prefetch the next item ----
         {
             const unsigned int sn = slot_i + nwaves, snn = sn + nwaves;
@@ -1168,7 +1169,7 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
             } else if (valid[q]) {
                 n_rays++;
                 bool blocked = false;
-                if (EXTRA) { Ctr cx = {0, 0, 0, 0}; const D3 rs = lpos + off[q]; blocked = extras_block<EXTRA>(sc, rs, E - rs, cx); }
+                if (EXTRA) { Ctr cx = {0, 0, 0, 0}; const int sj = lane + 64 * q; const D3 rs = lpos + mk(offsets[3 * sj], offsets[3 * sj + 1], offsets[3 * sj + 2]); blocked = extras_block<EXTRA>(sc, rs, E - rs, cx); }
                 if (blocked) escaped[q] = false;
                 else alive[q] = work;
             }
@@ -1256,7 +1257,7 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
             unsigned long long am0 = 0ull, am1 = 0ull;                    // (wave-uniform) samples still undecided
             int na = 128;
             for (; k < nc && have; ++k) {
-                if (!(k & 1) && na <= 64) break;                          // few samples left: the tail layout takes the rest of the chunk
+                if (TAIL && !(k & 1) && na <= 64) break;                  // few samples left: the tail layout takes the rest of the chunk
                 const float4 A = wc[k * 5], B1 = wc[k * 5 + 1], B2 = wc[k * 5 + 2], B3 = wc[k * 5 + 3], F = wc[k * 5 + 4];
                 // packed over the lane's two samples (.x = sample lane, .y = sample lane + 64)
                 const f2 g1 = pk_fma(splat(A.x), OX, pk_fma(splat(A.y), OY, pk_fma(splat(A.z), OZ, splat(A.w))));
@@ -1287,7 +1288,7 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
             // ---- tail layout: the na <= 64 undecided samples are compacted into sample slots; a lane is one (slot, candidate PAIR),
             //      so a pass tests 2 * 64 / W candidates against every remaining sample (W = 8, 16, 32 or 64 slots).  Same arithmetic,
             //      packed over the two candidates of a pair instead of over two samples ----
-            if (have && k < nc && na <= 64) {
+            if (TAIL && have && k < nc && na <= 64) {
                 const bool mine0 = alive[0] && !(bsum[0] > 0.0f), mine1 = alive[1] && !(bsum[1] > 0.0f);
                 if (mine0) wids[__popcll(am0 & lanemask_lt())] = (uint32_t)lane;
                 if (mine1) wids[__popcll(am0) + __popcll(am1 & lanemask_lt())] = (uint32_t)lane + 64u;
@@ -1369,7 +1370,8 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                 for (int q = 0; q < kPacketSlots; ++q) {
                     uint32_t m = (q ? alive[1] : alive[0]) ? (q ? unc[1] : unc[0]) : 0u;
                     if (m) {
-                        const D3 rs = lpos + (q ? off[1] : off[0]);
+                        const int sj = lane + 64 * q;
+                        const D3 rs = lpos + mk(offsets[3 * sj], offsets[3 * sj + 1], offsets[3 * sj + 2]);
                         SampleRay ray;
                         bool is_alive = prepare_sample(sc, rs, E - rs, ray);  // false: the ray misses the root box, nothing can block it
                         bool blocked = false;
@@ -1408,8 +1410,8 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
         } else {
             const int esc = (int)__popcll(__ballot(escaped[0])) + (int)__popcll(__ballot(escaped[1]));
             if (lane == 0) {                                               // finish_hit with the tabulated byte
-                if (fc.flags & 32u) sc.shadow_cache[rec.pad[0]] = (uint8_t)light_byte[esc];
-                else samples[rec.sample] = modulate(shaded, light_byte[esc]);
+                if (fc.flags & 32u) sc.shadow_cache[rec_cell] = (uint8_t)light_byte[esc];
+                else samples[rec_sample] = modulate(shaded, light_byte[esc]);
             }
         }
     }
@@ -2110,8 +2112,11 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
             if (!L.exact_shadow_tests) {
                 // default: fp32 classification, FP64 only for the pairs it cannot decide
                 const size_t lds_c = 4 * (size_t)kClsWaveF4 * sizeof(float4) + 128 * 3 * sizeof(float) + (64 * kPacketSlots + 1) * sizeof(uint32_t);
-                if (L.stats) hipLaunchKernelGGL((k_shadow_cls<EXTRA, true>), dim3(blocks), dim3(256), lds_c, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
-                else hipLaunchKernelGGL((k_shadow_cls<EXTRA, false>), dim3(blocks), dim3(256), lds_c, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
+                const auto args = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_c, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
+                };
+                if (first) { if (L.stats) args(k_shadow_cls<EXTRA, true, false>); else args(k_shadow_cls<EXTRA, false, false>); }
+                else { if (L.stats) args(k_shadow_cls<EXTRA, true, true>); else args(k_shadow_cls<EXTRA, false, true>); }
             } else if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
             else hipLaunchKernelGGL((k_shadow_test<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
             if ((e = hipGetLastError()) != hipSuccess) return e;
