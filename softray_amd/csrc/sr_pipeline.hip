@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
             UM = (f2){ok0 ? ut.x : -1.0f, ok1 ? ut.y : -1.0f};
         }
         const float hbm = cf.a0 + a1;
-        wum[lane] = UM.x; wum[lane + 64] = UM.y;                          // (the tail layout fetches a sample's umax by its index)
+        if (TAIL) { wum[lane] = UM.x; wum[lane + 64] = UM.y; }            // (the tail layout fetches a sample's umax by its index)
         bool have = __any(alive[0] || alive[1]);
         for (int base = 0; base < ntri && have; base += kClsCand) {
             const int nc = min(kClsCand, ntri - base);
@@ -1232,19 +1232,23 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                 wrecidx[lane] = ent;
                 // the same 20 floats once more, interleaved with the neighbour candidate's (pair p = lane / 2: float 2 f + (lane & 1)),
                 // so that the tail layout reads both candidates of a pair as packed operands
+                if (TAIL) {
                 float* pr = reinterpret_cast<float*>(wpair + (lane >> 1) * 10) + (lane & 1);
                 const float rec20[20] = {slab.n[0], slab.n[1], slab.n[2], N.y, W[0].x, W[0].y, W[0].z, W[0].w, W[1].x, W[1].y, W[1].z, W[1].w,
                                          W[2].x, W[2].y, W[2].z, W[2].w, G0, G0 <= -cf.a0 ? mc : 1e30f, G0 >= cf.a0 ? -1e30f : mc, 0.0f};
 #pragma unroll
                 for (int e = 0; e < 20; ++e) pr[2 * e] = rec20[e];
-            } else if (lane == nc && (nc & 1)) {
+                }
+            } else if (TAIL && lane == nc && (nc & 1)) {
                 // odd count: the last pair's second candidate is a null record -- in front of the surface point, "decided: miss" for every sample
                 float* pr = reinterpret_cast<float*>(wpair + (lane >> 1) * 10) + 1;
 #pragma unroll
                 for (int e = 0; e < 20; ++e) pr[2 * e] = e == 3 ? 1.0f : (e == 16 ? 1.0f : (e == 17 ? 1e30f : (e == 18 ? -1e30f : 0.0f)));
             }
-            wunc[lane] = 0u; wunc[lane + 64] = 0u;
-            if (lane < 4) wdead[lane] = 0u;
+            if (TAIL) {
+                wunc[lane] = 0u; wunc[lane + 64] = 0u;
+                if (lane < 4) wdead[lane] = 0u;
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             n_recs += (uint32_t)nc;
