@@ -81,6 +81,7 @@ struct PipelineLaunch {
     int32_t     row_first, row_limit; // compact rows [row_first, row_limit) of the frame are this launch's share
     int32_t     persistent_blocks;
     bool        per_lane_shadows; // force k_shadow (one lane per hit) instead of k_shadow_packet (cross-check)
+    int32_t     tile_queue_n2, tile_queue_rows; // (set by launch_pipeline) > 0: the hit queue of this band is tile-indexed
     int32_t     round2_node_budget; // later shaft rounds: a private walk gives up after this many nodes (0 = never)
     bool        per_lane_primary; // k_primary with private walks instead of the packet walk + camera-cone filter (cross-check)
     bool        per_lane_shaft;   // k_shaft (private walks) also for the first round instead of k_shaft_pkt (cross-check)

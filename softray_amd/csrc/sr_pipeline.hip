@@ -48,6 +48,28 @@ __device__ __forceinline__ unsigned long long lanemask_lt() {
     return lane == 0 ? 0ull : (~0ull >> (64u - lane));
 }
 
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup L runs on
+// XCD L % 8; the 1-D grid is mapped so that every XCD walks through its own 8x8-tile super-tiles (128 x 128 pixels,
+// neighbours share BVH nodes and triangle records in that XCD's L2), while at any time the eight XCDs work on different
+// super-tile columns of the same super-tile row (skewed by the row: balanced load).  Returns false for the padding of the
+// super-tile grid.  k_primary and k_shaft_pkt use the SAME mapping and the tile-aligned hit queue is indexed by the tile, so
+// the shaft walk of a tile runs on the XCD whose L2 the tile's primary walk has just warmed.
+__device__ __forceinline__ bool xcd_tile(int L, int width, int row_count, int& tile_x, int& tile_y) {
+    const int tiles_x = (width + 15) >> 4, tiles_y = (row_count + 15) >> 4;
+    const int spx = (((tiles_x + 7) >> 3) + 7) >> 3;                     // super-tile columns per XCD
+    const int k = L & 7, j = L >> 3;
+    const int sj = j >> 6, t = j & 63;
+    const int sy = sj / spx, sx = (sj - sy * spx) * 8 + ((k + sy) & 7);
+    tile_x = sx * 8 + (t & 7);
+    tile_y = sy * 8 + (t >> 3);
+    return tile_x < tiles_x && tile_y < tiles_y;
+}
+static int xcd_tile_grid(int width, int row_count) {
+    const int tiles_x = (width + 15) / 16, tiles_y = (row_count + 15) / 16;
+    const int spx = (((tiles_x + 7) / 8) + 7) / 8, sny = (tiles_y + 7) / 8;
+    return spx * 8 * sny * 64;
+}
+
 // --------------------------------------------------------------------------------------------------
 // k_primary
 // --------------------------------------------------------------------------------------------------
@@ -62,21 +84,8 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     int32_t* wnode = reinterpret_cast<int32_t*>(lds_pipe) + (size_t)__builtin_amdgcn_readfirstlane(wave) * levels;   // PKT: the wave's node stack
-    // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with its own L2), so workgroup
-    // L runs on XCD L % 8; the 1-D grid is mapped so that every XCD walks through its own 8x8-tile super-tiles
-    // (128 x 128 pixels, neighbours share BVH nodes and triangle records in that XCD's L2), while at any time the eight
-    // XCDs work on different super-tile columns of the same super-tile row (skewed by the row: balanced load).
     int tile_x, tile_y;
-    {
-        const int tiles_x = (fc.width + 15) >> 4, tiles_y = (row_count + 15) >> 4;
-        const int spx = (((tiles_x + 7) >> 3) + 7) >> 3;                 // super-tile columns per XCD
-        const int L = blockIdx.x, k = L & 7, j = L >> 3;
-        const int sj = j >> 6, t = j & 63;
-        const int sy = sj / spx, sx = (sj - sy * spx) * 8 + ((k + sy) & 7);
-        tile_x = sx * 8 + (t & 7);
-        tile_y = sy * 8 + (t >> 3);
-        if (tile_x >= tiles_x || tile_y >= tiles_y) return;              // padding of the super-tile grid (whole workgroup)
-    }
+    if (!xcd_tile((int)blockIdx.x, fc.width, row_count, tile_x, tile_y)) return;   // padding of the super-tile grid (whole workgroup)
     const int col = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
     const int brow = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);          // row inside this band
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
@@ -134,30 +143,37 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
                 if (ok) bounce_levels[(sbase + si) * (size_t)(fc.max_bounces + 1)] = color;
             }
         }
-        if (shadows || bounce) {                                             // active-ray compaction
-            unsigned long long m = __ballot(ok);
-            if (m) {
-                // pad_tiles (shaft path): every wave with a hit takes 64 consecutive queue entries, lane = entry, lanes without
-                // a hit mark theirs invalid -- a wave of k_shaft_pkt then owns exactly one 8x8-pixel tile of surface points
-                unsigned int base = 0;
-                const int leader = __ffsll((long long)m) - 1;
-                if (lane == leader) base = atomicAdd(hit_count, pad_tiles ? 64u : (unsigned int)__popcll(m));
-                base = __shfl(base, leader, 64);
-                if (pad_tiles && !ok) hits[base + (unsigned int)lane].sample = kInvalidHit;
-                if (ok) {
-                    HitRec r;
-                    r.pos[0] = h.pos.x; r.pos[1] = h.pos.y; r.pos[2] = h.pos.z;
-                    r.nrm[0] = h.nrm.x; r.nrm[1] = h.nrm.y; r.nrm[2] = h.nrm.z;
-                    r.sample = (uint32_t)(sbase + si);
-                    r.pad[0] = r.pad[1] = r.pad[2] = 0;
-                    if (bounce) {                                            // the queue holds the next RAY: origin, direction, level
-                        const D3 refl = dw - h.nrm * (2.0 * dot(dw, h.nrm));
-                        const D3 org = h.pos + h.nrm * 0.001;
-                        r.pos[0] = org.x; r.pos[1] = org.y; r.pos[2] = org.z;
-                        r.nrm[0] = refl.x; r.nrm[1] = refl.y; r.nrm[2] = refl.z;
-                        r.pad[0] = 1u;
-                    }
-                    hits[base + (pad_tiles ? (unsigned int)lane : (unsigned int)__popcll(m & lanemask_lt()))] = r;
+        if (shadows || bounce) {
+            HitRec r;
+            if (ok) {
+                r.pos[0] = h.pos.x; r.pos[1] = h.pos.y; r.pos[2] = h.pos.z;
+                r.nrm[0] = h.nrm.x; r.nrm[1] = h.nrm.y; r.nrm[2] = h.nrm.z;
+                r.sample = (uint32_t)(sbase + si);
+                r.pad[0] = r.pad[1] = r.pad[2] = 0;
+                if (bounce) {                                                // the queue holds the next RAY: origin, direction, level
+                    const D3 refl = dw - h.nrm * (2.0 * dot(dw, h.nrm));
+                    const D3 org = h.pos + h.nrm * 0.001;
+                    r.pos[0] = org.x; r.pos[1] = org.y; r.pos[2] = org.z;
+                    r.nrm[0] = refl.x; r.nrm[1] = refl.y; r.nrm[2] = refl.z;
+                    r.pad[0] = 1u;
+                }
+            }
+            if (pad_tiles) {
+                // shaft path: the queue is indexed by the TILE -- entry ((tile * n2 + sub-sample) * 4 + wave) * 64 + lane, lanes
+                // without a hit mark theirs invalid -- so a wave of k_shaft_pkt owns exactly one 8x8-pixel tile of surface
+                // points, no atomic is needed, and block b of k_shaft_pkt reads what block b of this kernel wrote
+                const int tiles_x = (fc.width + 15) >> 4;
+                const unsigned int slot = (((unsigned)(tile_y * tiles_x + tile_x) * (unsigned)n2 + (unsigned)si) * 4u + (unsigned)wave) * 64u + (unsigned)lane;
+                if (ok) hits[slot] = r;
+                else hits[slot].sample = kInvalidHit;
+            } else {                                                         // active-ray compaction
+                const unsigned long long m = __ballot(ok);
+                if (m) {
+                    unsigned int base = 0;
+                    const int leader = __ffsll((long long)m) - 1;
+                    if (lane == leader) base = atomicAdd(hit_count, (unsigned int)__popcll(m));
+                    base = __shfl(base, leader, 64);
+                    if (ok) hits[base + (unsigned int)__popcll(m & lanemask_lt())] = r;
                 }
             }
         }
@@ -599,7 +615,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
 // --------------------------------------------------------------------------------------------------
 template <bool STATS>
 __global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
-                                                   const unsigned int* __restrict__ hit_count, int cap, int levels,
+                                                   const unsigned int* __restrict__ hit_count, int cap, int levels, int tile_n2, int tile_rows,
                                                    unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
                                                    uint32_t* __restrict__ samples, unsigned int* __restrict__ work_count,
                                                    unsigned int* __restrict__ work_list, unsigned long long* stats) {
@@ -609,7 +625,15 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc
     // [levels][64] per-lane u bound, 16 bits: 0 = the lane's shaft misses the subtree, else 1 + the bound in 1/65534 rounded UP
     uint16_t* wbound = reinterpret_cast<uint16_t*>(wnode + levels) + lane;
     const unsigned int total = *hit_count;
-    const unsigned int slot_i = blockIdx.x * 256u + (unsigned)tid;
+    unsigned int slot_i = blockIdx.x * 256u + (unsigned)tid;
+    if (tile_n2 > 0) {
+        // tile-indexed queue (see k_primary): block b * n2 + sub-sample of this grid <-> block b of k_primary, same XCD
+        int tile_x, tile_y;
+        const int pb = (int)blockIdx.x / tile_n2, si = (int)blockIdx.x - pb * tile_n2;
+        if (!xcd_tile(pb, fc.width, tile_rows, tile_x, tile_y)) return;
+        const int tiles_x = (fc.width + 15) >> 4;
+        slot_i = ((unsigned)(tile_y * tiles_x + tile_x) * (unsigned)tile_n2 + (unsigned)si) * 256u + (unsigned)tid;
+    }
     HitRec rec;
     rec.sample = kInvalidHit;
     if (slot_i < total) rec = hits[slot_i];
@@ -1998,9 +2022,7 @@ static int pipe_stack_levels(const DevScene& sc, int mode) {
 template <int MODE, bool EXTRA, bool SUB, bool PKT>
 static hipError_t launch_primary_p(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples, int pad_tiles) {
     // 1-D grid over the padded super-tile grid (see the tile order in k_primary)
-    const int tiles_x = (L.fc.width + 15) / 16, tiles_y = (row_count + 15) / 16;
-    const int spx = (((tiles_x + 7) / 8) + 7) / 8, sny = (tiles_y + 7) / 8;
-    dim3 grid((unsigned)(spx * 8 * sny * 64));
+    dim3 grid((unsigned)xcd_tile_grid(L.fc.width, row_count));
     const int levels = pipe_stack_levels(L.sc, MODE);
     size_t lds = PKT ? (size_t)levels * 4 * 4 : (size_t)levels * 256 * 4;
     if (L.stats)
@@ -2083,8 +2105,10 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
             if (first && !L.per_lane_shaft) {
                 // round 1: one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
                 size_t lds = ((size_t)levels * 4 + (size_t)levels * 64 * 2) * 4;
-                if (L.stats) hipLaunchKernelGGL((k_shaft_pkt<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, levels, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
-                else hipLaunchKernelGGL((k_shaft_pkt<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, levels, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
+                const int tn2 = L.tile_queue_n2, trows = L.tile_queue_rows;
+                if (tn2 > 0) blocks = (unsigned)(xcd_tile_grid(L.fc.width, trows) * tn2);      // the grid of k_primary (x sub-samples)
+                if (L.stats) hipLaunchKernelGGL((k_shaft_pkt<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, levels, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
+                else hipLaunchKernelGGL((k_shaft_pkt<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, levels, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
             } else {
                 // later rounds (scattered hit points: private walks).  They collect from scratch (skip = 0): the order in which
                 // round 1 met a hit point's candidates was its wave's, not this walk's, so "skip the first cap" would not name
@@ -2175,6 +2199,11 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
         const int pad_tiles = (shadows && !(L.fc.flags & 32u) && L.fc.max_bounces == 0 && shaft_path<MODE>(L)) ? 1 : 0;
         e = L.fc.sub_pixel_res > 1 ? launch_primary_s<MODE, EXTRA, true>(L, row_begin, row_count, samples, pad_tiles)
                                    : launch_primary_s<MODE, EXTRA, false>(L, row_begin, row_count, samples, pad_tiles);
+        if (e == hipSuccess && pad_tiles) {
+            // the tile-indexed queue has one slot per pixel of every (whole) 16x16 tile and sub-sample: its "count" is its size
+            const unsigned int slots = (unsigned)(((L.fc.width + 15) / 16) * ((row_count + 15) / 16)) * 256u * (unsigned)n2;
+            e = hipMemsetD32Async((hipDeviceptr_t)L.counters, (int)slots, 1, L.stream);
+        }
         if (e != hipSuccess) return e;
         if (e1) { e = hipEventRecord(e1, L.stream); if (e != hipSuccess) return e; }
         if (L.fc.max_bounces > 0 && L.bounce_levels) {
@@ -2225,7 +2254,10 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
             if ((e = hipGetLastError()) != hipSuccess) return e;
         } else if (shadows) {
             // (queue entries are counted in whole tiles: see pad_tiles)
-            e = launch_shadow_t<MODE, EXTRA>(L, samples, (long long)((row_count + 15) / 16 * 16) * ((L.fc.width + 15) / 16 * 16) * n2);
+            PipelineLaunch T = L;                                    // this band's queue is tile-indexed (k_primary above)
+            T.tile_queue_n2 = pad_tiles ? n2 : 0;
+            T.tile_queue_rows = row_count;
+            e = launch_shadow_t<MODE, EXTRA>(T, samples, (long long)((row_count + 15) / 16 * 16) * ((L.fc.width + 15) / 16 * 16) * n2);
             if (e != hipSuccess) return e;
         }
         if (n2 > 1) {
