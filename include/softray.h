@@ -307,8 +307,9 @@ enum {
     SR_DBG_KERNEL_TIMING  = 7,   /* > 0: record a HIP event pair around every launch (sr_kernel_times); default off           */
     SR_DBG_EXACT_SHADOW_TESTS = 8, /* > 0: k_shadow_test decides every (sample, triangle) pair with the FP64 arithmetic (no
                                     fp32 classification): an independent schedule of the same result, kept as a cross-check */
-    SR_DBG_PER_LANE_SHAFT = 9,   /* > 0: first shaft round with private per-lane walks (k_shaft) instead of the wave-cooperative
-                                    packet walk (k_shaft_pkt): same lists up to order, same pixels; cross-check                */
+    SR_DBG_PER_LANE_SHAFT = 9,   /* bit 0: first shaft round with private per-lane walks (k_shaft) instead of the wave-cooperative
+                                    packet walk (k_shaft_pkt); bit 1: later rounds with private walks instead of one wave per hit
+                                    point (k_shaft_coop): same lists up to order, same pixels; cross-checks                     */
     SR_DBG_PER_LANE_PRIMARY = 10, /* > 0: primary rays with private per-lane walks instead of the packet walk + camera-cone filter */
     SR_DBG_ROUND2_NODES   = 11,  /* node budget of a private shaft walk of the later rounds (0 = unlimited): walks that exceed it hand
                                     their undecided samples to the exact fallback */

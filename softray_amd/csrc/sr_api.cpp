@@ -484,7 +484,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.persistent_blocks = s->num_cus * 8;
         P.per_lane_shadows = (f->flags & SR_F_PER_LANE_SHADOWS) != 0;
         P.exact_shadow_tests = s->dbg[SR_DBG_EXACT_SHADOW_TESTS] > 0;
-        P.per_lane_shaft = s->dbg[SR_DBG_PER_LANE_SHAFT] > 0;
+        P.per_lane_shaft = s->dbg[SR_DBG_PER_LANE_SHAFT] > 0 ? (int32_t)(s->dbg[SR_DBG_PER_LANE_SHAFT] & 3) : 0;
         P.per_lane_primary = s->dbg[SR_DBG_PER_LANE_PRIMARY] > 0;
         P.round2_node_budget = s->dbg[SR_DBG_ROUND2_NODES] >= 0 ? (int32_t)std::min<int64_t>(s->dbg[SR_DBG_ROUND2_NODES], 1 << 30) : 0;
         P.stats = d_stats;

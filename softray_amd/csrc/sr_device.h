@@ -84,7 +84,7 @@ struct PipelineLaunch {
     int32_t     tile_queue_n2, tile_queue_rows; // (set by launch_pipeline) > 0: the hit queue of this band is tile-indexed
     int32_t     round2_node_budget; // later shaft rounds: a private walk gives up after this many nodes (0 = never)
     bool        per_lane_primary; // k_primary with private walks instead of the packet walk + camera-cone filter (cross-check)
-    bool        per_lane_shaft;   // k_shaft (private walks) also for the first round instead of k_shaft_pkt (cross-check)
+    int32_t     per_lane_shaft;   // bit 0: k_shaft (private walks) for the first round instead of k_shaft_pkt, bit 1: for the later rounds instead of k_shaft_coop (cross-checks)
     bool        exact_shadow_tests; // k_shadow_test (every pair in FP64) instead of k_shadow_cls (fp32 classification first)
     unsigned long long* stats;  // device [8] or nullptr
     hipStream_t stream;

@@ -601,6 +601,132 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
 }
 
 // --------------------------------------------------------------------------------------------------
+// k_shaft_coop -- the later shaft rounds, ONE WAVE PER HIT POINT.  The hit points of a later round are scattered (0.8 % of
+// the frame's), so there is no packet to share a walk with, and a private walk is a chain of ~140 dependent node fetches
+// and ~400 triangle filters per lane: the kernel lasted as long as one such chain however few hit points there were (the
+// floor of a 1/8-frame rank), at 16 of 64 lanes active.  Here the 64 lanes of a wave work on ONE shaft: a frontier of
+// pending inner nodes and a queue of pending triangles live in LDS; a node pass lets up to 64 lanes fetch one frontier
+// node each, test both children's boxes and append what the shaft touches (inner children -> frontier, the triangles of
+// leaf children -> triangle queue); a triangle pass lets up to 64 lanes run shaft_touches on one triangle each and append
+// the candidates to the hit point's list.  The walk's depth in dependent fetches drops from hundreds to ~20 passes.
+// The arithmetic per node / triangle is k_shaft's; only the order of the list differs, which no later stage depends on
+// (launch_shadow_t: every round collects from scratch).  Frontier overflow = "truncated" (undecided samples go to the
+// exact fallback), like a full list.  Hit points are dealt round-robin to the waves of a fixed-size grid.
+// --------------------------------------------------------------------------------------------------
+constexpr int kCoopFrontier = 1024;      // pending inner nodes per wave
+constexpr int kCoopPasses = 1 << 16;     // passes per hit point (a 1M-triangle tree in full: 2^15 triangle passes)
+constexpr int kCoopTris = 1024;          // pending triangles per wave: < 64 before a node pass + at most 64 * 2 * 7 from it (default leaves)
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void k_shaft_coop(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
+                                                    const unsigned int* __restrict__ hit_count, unsigned int count_cap,
+                                                    const unsigned int* __restrict__ index_list, int cap,
+                                                    unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
+                                                    unsigned long long* stats) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    uint32_t* fr = reinterpret_cast<uint32_t*>(lds_pipe) + (size_t)wave * (kCoopFrontier + kCoopTris);
+    uint32_t* tq = fr + kCoopFrontier;
+    const unsigned int total = min(*hit_count, count_cap);
+    const unsigned long long lt = lanemask_lt();
+    uint32_t nodes = 0, slabs = 0, items = 0;                         // wave-level
+    const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
+    const float R = (float)fc.light_radius * 1.00001f + 1e-30f;
+    float ext = 0.0f;
+    for (int a = 0; a < 3; ++a) ext = fmaxf(ext, (float)(sc.root.max[a] - sc.root.min[a]));
+    const float pad = ext * 3.0517578125e-5f;                          // 2^-15 * extent (boxes carry 2^-16 already)
+    const int nbits = sc.bnode_bits, qmax = (1 << (31 - nbits)) - 1;   // frontier word = node | quantised u bound (rounded UP)
+    const float qinv = 1.0f / (float)qmax * 1.000001f;
+    const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
+    // hit points are dealt to the waves of the (fixed-size) grid round-robin: wave-uniform loop bounds, every wave reaches the exit
+    const unsigned int wave_id = blockIdx.x * 4u + (unsigned)wave, wave_count = gridDim.x * 4u;
+    for (unsigned int item = wave_id; item < total; item += wave_count) {
+        const unsigned int h = index_list[item];
+        const HitRec rec = hits[h];
+        items++;
+        const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;   // ShadowMethod.cs:151
+        const float ex = (float)(E.x - sc.root.centre[0]), ey = (float)(E.y - sc.root.centre[1]), ez = (float)(E.z - sc.root.centre[2]);
+        const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
+        const float ix = slab_inv(dx), iy = slab_inv(dy), iz = slab_inv(dz);
+        const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
+        const f2 OI01 = {-ex * ix, -ey * iy}, OI20 = {-ez * iz, -ex * ix}, OI12 = {-ey * iy, -ez * iz};
+        const f2 RI01 = {-ix, -iy}, RI20 = {-iz, ix}, RI12 = {iy, iz};
+        const ShaftRay sr = make_shaft_ray(sc, fc, E, lpos);
+        int32_t* out = cand + (size_t)item * cap;
+        int count = 0, nf = 1, nt = 0;                                 // wave-uniform
+        bool truncated = false, umbra = false;
+        if (lane == 0) fr[0] = (uint32_t)qmax << nbits;                // the root, u <= 1
+        // (a pass budget bounds the loop whatever the tree holds: a walk of that many passes gives up as "truncated")
+        for (int passes = 0; (nf > 0 || nt > 0) && !truncated && !umbra; ++passes) {
+            if (passes >= kCoopPasses) truncated = true;
+            else if (nt >= 64 || nf == 0) {
+                // ---- triangle pass: the newest (up to) 64 pending triangles ----
+                const int take = min(nt, 64);
+                nt -= take;
+                const bool act = lane < take;
+                const int tri = act ? (int)tq[nt + lane] : 0;
+                slabs += (uint32_t)take;
+                const int touch = shaft_touches(sc.bslab[tri], sr, act);
+                const unsigned long long m = __ballot(act && touch != 0);
+                const int pos = count + __popcll(m & lt);
+                if (act && touch != 0 && pos < cap) out[pos] = tri;
+                count += __popcll(m);
+                truncated = count > cap;
+                count = min(count, cap);
+                umbra = __ballot(act && touch == 2) != 0ull;
+            } else {
+                // ---- node pass: the newest (up to) 64 frontier nodes ----
+                const int take = min(nf, 64);
+                nf -= take;
+                const bool act = lane < take;
+                const uint32_t w = act ? fr[nf + lane] : 0u;
+                nodes += (uint32_t)take;
+                const BvhNode n = sc.bnodes[w & ((1u << nbits) - 1u)];
+                const float nu = (float)(w >> nbits) * qinv;
+                const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
+                const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
+                float a0, b0, a1, b1;                                  // child u-intervals [a, b]
+                node_slabs(n, I01, I20, I12, B0, B1, B2, a0, b0, a1, b1);
+                a0 = fmaxf(a0, umin); a1 = fmaxf(a1, umin);
+                b0 = fminf(b0, nu); b1 = fminf(b1, nu);
+                const bool h0 = act && n.n0 >= 0 && a0 <= b0, h1 = act && n.n1 >= 0 && a1 <= b1;
+                const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
+                const unsigned long long m0 = __ballot(i0), m1 = __ballot(i1);
+                const int add = __popcll(m0) + __popcll(m1);
+                // the triangles of leaf children (exclusive prefix sum of the <= 5-bit counts by ballots)
+                const int c0 = (h0 && n.n0 > 0) ? min(n.n0, 15) : 0, c1 = (h1 && n.n1 > 0) ? min(n.n1, 15) : 0;
+                const int cl = c0 + c1;                                // <= 14 with the default <= 7 triangles per leaf
+                int before = 0, sum = 0;
+#pragma unroll
+                for (int b = 0; b < 5; ++b) {
+                    const unsigned long long mb = __ballot((cl >> b) & 1);
+                    before += __popcll(mb & lt) << b;
+                    sum += __popcll(mb) << b;
+                }
+                // no room (frontier: very wide shafts; triangle queue: only with leaves of > 7 triangles): give up as "truncated"
+                truncated = nf + add > kCoopFrontier || nt + sum > kCoopTris;
+                if (!truncated) {
+                    // inner children -> frontier
+                    if (i0) fr[nf + __popcll(m0 & lt)] = (uint32_t)n.c0 | ((uint32_t)min(qmax, (int)(fminf(1.0f, fmaxf(0.0f, b0)) * (float)qmax) + 1) << nbits);
+                    if (i1) fr[nf + __popcll(m0) + __popcll(m1 & lt)] = (uint32_t)n.c1 | ((uint32_t)min(qmax, (int)(fminf(1.0f, fmaxf(0.0f, b1)) * (float)qmax) + 1) << nbits);
+                    nf += add;
+                    // leaf triangles -> triangle queue
+                    uint32_t* dst = tq + nt + before;
+                    for (int q = 0; q < c0; ++q) dst[q] = (uint32_t)(n.c0 + q);
+                    for (int q = 0; q < c1; ++q) dst[c0 + q] = (uint32_t)(n.c1 + q);
+                    nt += sum;
+                }
+            }
+        }
+        if (lane == 0) cand_count[item] = umbra ? kUmbraItem : ((unsigned)count | (truncated ? kTruncated : 0u));
+    }
+    if (STATS) {
+        block_stat_add(&stats[6], &stats[10], &stats[11], &stats[14], nodes, slabs, items, nodes);
+        block_stat_add(&stats[15], &stats[15], &stats[15], &stats[15], slabs, 0u, 0u, 0u);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
 // k_shaft_pkt -- the first shaft round as a wave-cooperative PACKET walk.  A wave owns 64 consecutive entries of the
 // tile-aligned hit queue = the surface points of one 8x8-pixel tile, whose shafts all end in the same light and start
 // within a few thousandths of each other: their walks visit nearly the same nodes.  So the wave walks the BVH ONCE --
@@ -2102,17 +2228,25 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         {
             const int levels = pipe_stack_levels(L.sc, MODE_BVH);
             unsigned blocks = (unsigned)((max_items + 255) / 256);
-            if (first && !L.per_lane_shaft) {
+            if (first && !(L.per_lane_shaft & 1)) {
                 // round 1: one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
                 size_t lds = ((size_t)levels * 4 + (size_t)levels * 64 * 2) * 4;
                 const int tn2 = L.tile_queue_n2, trows = L.tile_queue_rows;
                 if (tn2 > 0) blocks = (unsigned)(xcd_tile_grid(L.fc.width, trows) * tn2);      // the grid of k_primary (x sub-samples)
                 if (L.stats) hipLaunchKernelGGL((k_shaft_pkt<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, levels, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
                 else hipLaunchKernelGGL((k_shaft_pkt<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, levels, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
-            } else {
-                // later rounds (scattered hit points: private walks).  They collect from scratch (skip = 0): the order in which
-                // round 1 met a hit point's candidates was its wave's, not this walk's, so "skip the first cap" would not name
+            } else if (!first && !(L.per_lane_shaft & 2)) {
+                // later rounds (scattered hit points): one wave per hit point, see k_shaft_coop.  They collect from scratch (skip = 0):
+                // the order in which round 1 met a hit point's candidates was its wave's, so "skip the first cap" would not name
                 // the same triangles; re-testing a candidate is harmless (it did not block the samples that are still undecided)
+                const size_t lds = 4 * (size_t)(kCoopFrontier + kCoopTris) * 4;
+                // 32 KB of LDS per workgroup = 5 resident per CU; a grid of ~6 times that many lets the dispatcher balance the walks
+                // (headline frame: 1280 workgroups 0.90 ms, 2048 0.78, 8192 0.73)
+                const unsigned cblocks = (unsigned)std::min<long long>((max_items + 3) / 4, (long long)L.persistent_blocks * 4);
+                if (L.stats) hipLaunchKernelGGL((k_shaft_coop<true>), dim3(cblocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, cap, L.round_cand_count[round], L.round_cand[round], L.stats);
+                else hipLaunchKernelGGL((k_shaft_coop<false>), dim3(cblocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, count_cap, ilist, cap, L.round_cand_count[round], L.round_cand[round], L.stats);
+            } else {
+                // private per-lane walks: the first round as a cross-check of the packet walk, the later rounds as one of k_shaft_coop
                 size_t lds = (size_t)levels * 256 * 4;
                 unsigned int* wc = first ? work0 : nullptr;
                 unsigned int* wl = first ? L.round_list[0] : nullptr;

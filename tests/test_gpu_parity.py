@@ -408,9 +408,10 @@ def test_fp32_classification_against_exact_schedule():
 
 
 def test_packet_shaft_walk_against_private_walks():
-    """k_shaft_pkt (one wave-cooperative walk per 8x8-pixel tile of surface points, tile-aligned hit queue) against k_shaft
-    (one private walk per lane) and the oracle: tiles that straddle the silhouette, odd frame sizes (partial tiles), sub-pixel
-    sampling (several queue tiles per pixel tile), tiny lists (round 2 re-collects from scratch, then the fallback)."""
+    """k_shaft_pkt (one wave-cooperative walk per 8x8-pixel tile of surface points, tile-aligned hit queue) and k_shaft_coop
+    (later rounds: one wave per hit point) against k_shaft (one private walk per lane; bit 0: in round 1, bit 1: in round 2)
+    and the oracle: tiles that straddle the silhouette, odd frame sizes (partial tiles), sub-pixel sampling (several queue
+    tiles per pixel tile), tiny lists (round 2 re-collects from scratch, then the fallback)."""
     v9, argb, bmin, bmax = unit_cube_scene(30000)
     g = sa.GpuScene(0); o = orc.Scene()
     for s_ in (g, o):
@@ -422,7 +423,7 @@ def test_packet_shaft_walk_against_private_walks():
         for caps in (None, (2, 3), (5, 64)):
             g.debug_set(sa._lib.DBG_ROUND_CAP0, caps[0] if caps else -1)
             g.debug_set(sa._lib.DBG_ROUND_CAP1, caps[1] if caps else -1)
-            for per_lane in (0, 1):
+            for per_lane in (0, 1, 2, 3):
                 g.debug_set(sa._lib.DBG_PER_LANE_SHAFT, per_lane)
                 got, _ = g.render(as_sr(f, sa.MODE_BVH))
                 assert np.array_equal(got, want), (kw, caps, per_lane)
