@@ -378,6 +378,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         if (s->dbg[SR_DBG_BAND_SAMPLES] > 0) kMaxBandSamples = s->dbg[SR_DBG_BAND_SAMPLES];
         if (s->dbg[SR_DBG_ROUND_CAP0] > 0) round_cap[0] = (int)std::min<int64_t>(s->dbg[SR_DBG_ROUND_CAP0], sr::pipeline_round_cap_max(0));
         if (s->dbg[SR_DBG_ROUND_CAP1] > 0) round_cap[1] = (int)std::min<int64_t>(s->dbg[SR_DBG_ROUND_CAP1], sr::pipeline_round_cap_max(1));
+        if (s->dbg[SR_DBG_EXACT_SHADOW_TESTS] > 0) round_cap[1] = std::min(round_cap[1], 64);   // k_shadow_test keeps a list in one wave's registers
     }
     // Two halves of the frame (16-row granularity) run as two pipelines on two internal streams, each with its own scratch
     // set; a half that exceeds its share of the band budget is processed in sequential bands on its stream.  A static

@@ -1644,6 +1644,9 @@ __global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc,
     const int tid = threadIdx.x, lane = tid & 63;
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
     const unsigned int total = min(*ray_count, ray_cap);
+    // the grid is sized for a full ray list; with a short one most workgroups would only queue up at the work counter (thousands
+    // of atomics on one address) -- they leave before touching it: 16 lanes per ray remain
+    if ((unsigned long long)blockIdx.x * 1024ull >= (unsigned long long)total * 16ull) return;
     const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
     const float kInfl = 1.0f + 9.5367431640625e-7f;          // 1 + 2^-20
     Ctr sec = {0, 0, 0, 0};
@@ -2422,7 +2425,9 @@ hipError_t launch_pipeline(const PipelineLaunch& L) {
 size_t pipeline_hit_record_bytes() { return sizeof(HitRec); }
 size_t pipeline_static_cells() { return (size_t)kStaticRes * kStaticRes * kStaticRes; }
 int pipeline_round_cap(int round) { return kRoundCap[round]; }   // default list length of a round
-int pipeline_round_cap_max(int) { return 64; }                   // longest list the kernels handle (sr_debug_set hooks)
+// longest list the kernels handle (sr_debug_set hooks): 64 in the first round and wherever k_shadow_test keeps the list in the
+// registers of one wave; the later rounds of the default path (k_shaft_coop, k_shadow_cls) read and write it in chunks
+int pipeline_round_cap_max(int round) { return round == 0 ? 64 : 1024; }
 size_t pipeline_round_state_bytes() { return sizeof(RoundState); }
 
 }  // namespace sr

@@ -420,7 +420,7 @@ def test_packet_shaft_walk_against_private_walks():
     for kw in (dict(), dict(sub_pixel_res=2), dict(yaw_deg=10.0, pitch_deg=80.0), dict(start_row=5, end_row=70)):
         f = make_frame(117, 91, depth=1.5, shadows=True, **kw)
         want, _ = o.render(f, threads=NCPU)
-        for caps in (None, (2, 3), (5, 64)):
+        for caps in (None, (2, 3), (5, 64), (3, 200)):
             g.debug_set(sa._lib.DBG_ROUND_CAP0, caps[0] if caps else -1)
             g.debug_set(sa._lib.DBG_ROUND_CAP1, caps[1] if caps else -1)
             for per_lane in (0, 1, 2, 3):
