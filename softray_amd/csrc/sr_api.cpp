@@ -144,15 +144,20 @@ int sync_geometry(sr_scene* s, uint32_t need_mode) {
     }
     if (need_mode == SR_MODE_BVH && s->bvh_dirty && !s->bvh_on_device) {
         SR_HIP(s->d_bnodes.upload(s->bvh.nodes));
-        std::vector<sr::Rec128> ordered(s->bvh.order.size());
-        for (size_t i = 0; i < ordered.size(); ++i) ordered[i] = s->tri_recs[s->bvh.order[i]];
-        SR_HIP(s->d_btris.upload(ordered));
-        std::vector<sr::TriSlab> slabs(s->bvh.order.size());
-        for (size_t i = 0; i < slabs.size(); ++i) {
-            const double* p = &s->v9[(size_t)s->bvh.order[i] * 9];
-            slabs[i] = sr::make_tri_slab({p[0], p[1], p[2]}, {p[3], p[4], p[5]}, {p[6], p[7], p[8]}, s->root.centre);
-        }
-        SR_HIP(s->d_bslab.upload(slabs));
+        // the leaf-order copies of the FP64 records and the fp32 shaft records are made on the device from the TriangleIndex-order
+        // arrays that are there already: only the order (4 B per triangle) travels
+        const size_t n = s->bvh.order.size();
+        DBuf d_order, d_slab;
+        SR_HIP(d_order.upload(s->bvh.order));
+        SR_HIP(d_slab.reserve(n * sizeof(sr::TriSlab)));
+        SR_HIP(sr::make_slabs_device((const double*)s->d_v9.p, (int)n, s->root, (sr::TriSlab*)d_slab.p, nullptr));
+        SR_HIP(s->d_btris.reserve(n * sizeof(sr::Rec128)));
+        SR_HIP(s->d_bslab.reserve(n * sizeof(sr::TriSlab)));
+        SR_HIP(sr::gather_records_device((int)n, (const unsigned int*)d_order.p, (const sr::Rec128*)s->d_tris.p, (sr::Rec128*)s->d_btris.p,
+                                         (const sr::TriSlab*)d_slab.p, (sr::TriSlab*)s->d_bslab.p, nullptr));
+        SR_HIP(hipDeviceSynchronize());
+        d_order.release();
+        d_slab.release();
         s->bvh_num_nodes = s->bvh.nodes.size();
         s->bvh_dirty = false;
         s->cam_valid = false;

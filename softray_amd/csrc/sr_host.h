@@ -32,7 +32,6 @@ private:
 Rec128 make_triangle_record(Vec3 v1, Vec3 v2, Vec3 v3, uint32_t color, int32_t aux);  // Triangle.cs:29-57
 Rec128 make_sphere_record(Vec3 centre, double radius, uint32_t color);                // Sphere.cs:26-33
 Rec128 make_plane_record(Vec3 point, Vec3 normal, uint32_t color);                    // Plane.cs:22-29
-TriSlab make_tri_slab(Vec3 v1, Vec3 v2, Vec3 v3, const double centre[3]);                   // shaft-walk prefilter record
 RootBox make_root_box(const double bmin[3], const double bmax[3]);                    // AxisAlignedBox.cs:16-28
 
 // ---- reference tree (SpatialSubdivision.cs:49-315) flattened ----
@@ -55,7 +54,8 @@ struct Bvh {
     int32_t depth = 0;
     bool built = false;
 };
-void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int leaf_max = 7);
+// threads: 0 = the host's cores (at most 16); the tree does not depend on it
+void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int leaf_max = 7, int threads = 0);
 
 // ---- Instance / Renderer helpers ----
 void instance_matrices(const double position[3], double yaw, double pitch, double roll,

@@ -173,9 +173,11 @@ struct Tmp {
 
 #define LB_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return e__; } while (0)
 
-// make_tri_slab (sr_host.cpp) on the device: the fp32 shaft / classification record of every triangle, TriangleIndex order.
-// FP64 arithmetic like the host's; the records are conservative filters, so the two builds need not agree to the last bit
-// (a zero record = "never filtered" is always admissible).
+// The fp32 shaft / classification record of every triangle (TriSlab, sr_types.h), TriangleIndex order, for both the host and
+// the device build: unit normal + offset, three in-plane unit edge normals pointing at the opposite vertex + offsets, computed
+// in FP64 relative to the root centre and rounded once.  Degenerate / needle-thin triangles, and those whose "zero" normal the
+// reference replaces by (1,0,0) (Triangle.cs:42-43: it then accepts hits in the plane x = v1.x that need not be near the
+// geometric triangle), get an all-zero record = "never filtered", which is always admissible.
 __global__ void k_make_slabs(const double* __restrict__ v9, int n, double cx, double cy, double cz, TriSlab* __restrict__ out) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -227,6 +229,17 @@ __global__ void k_make_slabs(const double* __restrict__ v9, int n, double cx, do
 hipError_t make_slabs_device(const double* d_v9, int n, const RootBox& root, TriSlab* d_out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_make_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_v9, n, root.centre[0], root.centre[1], root.centre[2], d_out);
+    return hipGetLastError();
+}
+
+// Leaf-order copies of the FP64 records and the fp32 shaft records: out[p] = in[order[p]] (the host SAH build ships only its
+// order; gathering 128 + 64 bytes per triangle on the host and uploading the copies cost more than the build itself).
+hipError_t gather_records_device(int n, const unsigned int* d_order, const Rec128* d_tris, Rec128* d_btris, const TriSlab* d_slab_in,
+                                 TriSlab* d_bslab, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const long long pieces = (long long)n * 8;
+    hipLaunchKernelGGL(k_lbvh_gather, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, n, d_order, (const uint4*)d_tris, (uint4*)d_btris,
+                       (const uint4*)d_slab_in, (uint4*)d_bslab);
     return hipGetLastError();
 }
 

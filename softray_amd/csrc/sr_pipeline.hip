@@ -2110,7 +2110,7 @@ __global__ __launch_bounds__(256) void k_cam_cones(const Rec128* __restrict__ bt
     const Rec128* r = &btris[i];
     const TriSlab sl = bslab[i];
     CamCone c;
-    const bool degenerate = sl.n[0] == 0.0f && sl.n[1] == 0.0f && sl.n[2] == 0.0f;   // make_tri_slab: no usable planes
+    const bool degenerate = sl.n[0] == 0.0f && sl.n[1] == 0.0f && sl.n[2] == 0.0f;   // k_make_slabs: no usable planes
     if (degenerate) {
         for (int k = 0; k < 2; ++k) { c.w12x[k] = c.w12y[k] = c.w12z[k] = c.w3nx[k] = c.w3ny[k] = c.w3nz[k] = 0.0f; c.m12[k] = c.m3n[k] = 1e30f; }
     } else {
