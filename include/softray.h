@@ -197,6 +197,9 @@ int  sr_build(sr_scene*, uint32_t modes, int32_t max_depth, int32_t max_per_leaf
 int  sr_tree_stats(const sr_scene*, int32_t out[4]);
 /* the library's own BVH: out = depth, inner nodes, triangles, 1 if it was built on the device */
 int  sr_bvh_stats(const sr_scene*, int64_t out[4]);
+/* diagnostics: FNV-1a hashes of the host-built BVH's node array and of its leaf-ordered triangle indices (the host build must not
+ * depend on the number of threads it ran on); SR_ERR_NOT_BUILT for a device-built tree */
+int  sr_bvh_digest(const sr_scene*, uint64_t out[2]);
 
 /* Renderer.Render() for one Instance, raytrace path (Renderer.cs:701-778 -> RaytraceGeometry :1501 ->
  * RaytraceBlock :1690).  pixels = caller-owned int[W*H] ARGB, row-major pixels[row*W+col]
@@ -313,6 +316,7 @@ enum {
     SR_DBG_PER_LANE_PRIMARY = 10, /* > 0: primary rays with private per-lane walks instead of the packet walk + camera-cone filter */
     SR_DBG_ROUND2_NODES   = 11,  /* node budget of a private shaft walk of the later rounds (0 = unlimited): walks that exceed it hand
                                     their undecided samples to the exact fallback */
+    SR_DBG_BUILD_THREADS  = 12,  /* threads of the host BVH build (default: the host's cores, at most 16); read by the next sr_build    */
     SR_DBG_COUNT          = 16
 };
 int  sr_debug_set(sr_scene*, int32_t key, int64_t value);

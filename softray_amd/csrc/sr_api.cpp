@@ -773,7 +773,8 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         s->bvh_dirty = false;
         s->cam_valid = false;
     } else if (modes & (1u << SR_MODE_BVH)) {
-        sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(15, s->dbg[SR_DBG_BVH_LEAF]) : 7);
+        sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(15, s->dbg[SR_DBG_BVH_LEAF]) : 7,
+                      s->dbg[SR_DBG_BUILD_THREADS] > 0 ? (int)std::min<int64_t>(64, s->dbg[SR_DBG_BUILD_THREADS]) : 0);
         if (s->bvh.depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
         s->bvh_on_device = false;
         s->bvh_dirty = true;
@@ -801,6 +802,21 @@ int sr_bvh_stats(const sr_scene* s, int64_t out[4]) {
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
     if (!s->bvh.built) return fail(SR_ERR_NOT_BUILT, "BVH not built");
     out[0] = s->bvh.depth; out[1] = (int64_t)(s->bvh_on_device ? s->bvh_num_nodes : s->bvh.nodes.size()); out[2] = (int64_t)s->tri_recs.size(); out[3] = s->bvh_on_device ? 1 : 0;
+    return SR_OK;
+}
+
+int sr_bvh_digest(const sr_scene* s, uint64_t out[2]) {
+    if (s && !s->parts.empty()) s = s->parts[0];
+    if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
+    if (!s->bvh.built || s->bvh_on_device) return fail(SR_ERR_NOT_BUILT, "no host-built BVH");
+    auto fnv = [](const void* p, size_t bytes) {
+        uint64_t h = 1469598103934665603ull;
+        const unsigned char* c = (const unsigned char*)p;
+        for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+        return h;
+    };
+    out[0] = fnv(s->bvh.nodes.data(), s->bvh.nodes.size() * sizeof(sr::BvhNode));
+    out[1] = fnv(s->bvh.order.data(), s->bvh.order.size() * sizeof(int32_t));
     return SR_OK;
 }
 

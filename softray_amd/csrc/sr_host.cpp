@@ -400,7 +400,7 @@ struct BvhBuilder {
 
     ChildRef build_all(int n, const Bounds& all) {
         std::vector<Task> tasks;
-        Dest top{&out.nodes, nullptr, 0, 0, threads > 1 ? &tasks : nullptr};
+        Dest top{&out.nodes, nullptr, 0, 0, n > 2 * kTaskSize ? &tasks : nullptr};   // (also with one thread: same node numbering)
         ChildRef r = build(0, n, 1, all, 0, top, -1, 0);
         out.depth = top.depth;
         if (tasks.empty()) return r;
@@ -451,7 +451,7 @@ void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int
     BvhBuilder bb(out, root, std::ldexp(ext > 0 ? ext : 1.0, -16));
     bb.kLeafMax = std::min(15, std::max(1, leaf_max));
     if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
-    bb.threads = n > (size_t)2 * BvhBuilder::kTaskSize ? std::min(threads, (int)BvhBuilder::kMaxThreads) : 1;
+    bb.threads = n > (size_t)2 * BvhBuilder::kTaskSize ? std::max(1, std::min(threads, (int)BvhBuilder::kMaxThreads)) : 1;
     bb.buf[0].resize(n);
     bb.buf[1].resize(n);
     out.order.resize(n);

@@ -97,6 +97,12 @@ class GpuScene:
         _check(_lib.lib().sr_bvh_stats(self._h, _p(out)))
         return tuple(int(x) for x in out)
 
+    def bvh_digest(self):
+        """(hash of the node array, hash of the leaf-ordered triangle indices) of the host-built BVH."""
+        out = np.zeros(2, dtype=np.uint64)
+        _check(_lib.lib().sr_bvh_digest(self._h, _p(out)))
+        return tuple(int(x) for x in out)
+
     # ---- Render() ----
     @staticmethod
     def pixel_count(frame):

@@ -66,6 +66,23 @@ def test_library_never_reads_the_environment():
         s.debug_set(99, 1)
 
 
+def test_host_bvh_build_does_not_depend_on_the_thread_count():
+    """The binned-SAH build spreads its passes and subtrees over the host's cores; tree, node numbering and triangle order must be
+    those of the single-threaded build (order-independent reductions, stable partition, subtrees appended in range order)."""
+    v9, argb = sa.make_random_triangles(200000, 4711, space=0.95, extent=0.05, origin=-0.5, opaque=True)
+    digests, stats = set(), set()
+    for threads in (1, 2, 5, 16):
+        s = sa.GpuScene(device=-1)                   # host-only scene: the build is host work
+        s.set_triangles(v9, argb, np.array([-0.5] * 3), np.array([0.5] * 3))
+        s.debug_set(sa._lib.DBG_BUILD_THREADS, threads)
+        s.build((sa.MODE_BVH,))
+        digests.add(s.bvh_digest())
+        stats.add(s.bvh_stats())
+    assert len(digests) == 1 and len(stats) == 1, (digests, stats)
+    depth, nodes, tris, on_device = next(iter(stats))
+    assert tris == 200000 and on_device == 0 and 200000 / 7 <= nodes < 200000 and 15 <= depth <= 60
+
+
 def test_no_cpu_fallback():
     s = sa.GpuScene(device=-1)                       # host-only scene
     v9, argb, bmin, bmax = load_obj3ds()
