@@ -716,6 +716,10 @@ __global__ __launch_bounds__(256) void k_shaft_coop(DevScene sc, FrameConst fc, 
                     for (int q = 0; q < c1; ++q) dst[c0 + q] = (uint32_t)(n.c1 + q);
                     nt += sum;
                 }
+                // the next pass reads what other lanes of this wave have just queued (LDS executes a wave's accesses in order;
+                // the fence keeps the compiler from moving them)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
             }
         }
         if (lane == 0) cand_count[item] = umbra ? kUmbraItem : ((unsigned)count | (truncated ? kTruncated : 0u));
