@@ -15,7 +15,8 @@ frame left in HBM is reported beside it (`hbm_resident`).
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): the frame is row-tiled in interleaved
 16-row strips, every rank renders its strips into a compact device buffer and ONE RCCL gather over
-xGMI collects the strips on rank 0 ("scaling": "strong" -- the frame is fixed), which reads it back.
+xGMI collects the strips on rank 0 ("scaling": "strong" -- the frame is fixed), which reads it back.  The gather
+is asynchronous (RCCL's stream), de-interleave and read-back follow it on the copy stream: frame k+1 renders meanwhile.
 `--in-library` (single process): the same split behind the C ABI (sr_create_multi).
 """
 import argparse
@@ -268,6 +269,7 @@ def main():
     rendered = [torch.cuda.Event() for _ in range(2)]
     copied = [torch.cuda.Event() for _ in range(2)]
     copied_once = [False, False]
+    pending = [None, None]                                           # gather handles of the two buffer sets
     state = {"k": 0, "readback": True}
 
     def step():
@@ -275,13 +277,25 @@ def main():
         state["k"] += 1
         if args.static_shadows:
             g.reset_shadow_cache()                                   # every step generates the whole cache again
-        if state["readback"] and copied_once[k]:
+        if copied_once[k] and (state["readback"] or sg):
             stream.wait_event(copied[k])                             # surface k is free once its last read-back has finished
+        if sg and pending[k] is not None:
+            pending[k].wait()                                        # buffer set k: its previous gather has left / arrived (long ago)
         target = sg[k].local if sg else surfaces[k]
         g.render_device(frame, target.data_ptr(), stream.cuda_stream)
         if sg:
-            sg[k].exchange()                                          # RCCL gather over xGMI + de-interleave on rank 0
-        if rank == 0 and state["readback"]:
+            # the gather is queued behind this frame's kernels and runs on RCCL's stream; the de-interleave and the read-back
+            # follow it on the copy stream, so the compute stream goes straight on to the next frame (two buffer sets)
+            pending[k] = sg[k].start()
+            if rank == 0:
+                with torch.cuda.stream(copy_stream):
+                    pending[k].wait()
+                    sg[k].finish()
+                    if state["readback"]:
+                        host[k].copy_(surfaces[k].view(-1), non_blocking=True)
+                    copied[k].record(copy_stream)
+                copied_once[k] = True
+        elif rank == 0 and state["readback"]:
             rendered[k].record(stream)
             with torch.cuda.stream(copy_stream):
                 copy_stream.wait_event(rendered[k])

@@ -41,18 +41,30 @@ class StripGather:
             self.uniform = self.maxc > 0 and all(c == self.maxc for c in self.counts)
             self.rows_all = torch.cat(self.row_idx) if self.uniform else None
 
-    def exchange(self):
-        """dist.gather (RCCL send/recv over xGMI on GPUs, gloo on CPU) + de-interleave on rank 0."""
+    def start(self):
+        """Enqueue the gather (RCCL send/recv over xGMI on GPUs, gloo on CPU) behind the work already queued on the current stream
+        and return its handle (None for one rank): the caller's stream is free for the next frame while the strips travel."""
         if self.world == 1:
-            if self.rank == 0:
-                self.full[self.row_idx[0]] = self.local[: self.counts[0]].view(-1, self.width)
-            return self.full
-        dist.gather(self.local, self.gather_list, dst=0)
-        if self.rank == 0:
-            if self.uniform:
-                self.full[self.rows_all] = self.gbuf.view(-1, self.width)
-            else:
-                for k in range(self.world):
-                    if self.counts[k]:
-                        self.full[self.row_idx[k]] = self.gather_list[k][: self.counts[k]].view(-1, self.width)
+            return None
+        return dist.gather(self.local, self.gather_list, dst=0, async_op=True)
+
+    def finish(self):
+        """De-interleave on rank 0 (on the current stream; the gather must have been waited for on it)."""
+        if self.rank != 0:
+            return None
+        if self.world == 1:
+            self.full[self.row_idx[0]] = self.local[: self.counts[0]].view(-1, self.width)
+        elif self.uniform:
+            self.full[self.rows_all] = self.gbuf.view(-1, self.width)
+        else:
+            for k in range(self.world):
+                if self.counts[k]:
+                    self.full[self.row_idx[k]] = self.gather_list[k][: self.counts[k]].view(-1, self.width)
         return self.full
+
+    def exchange(self):
+        """start() + wait + finish() on the current stream."""
+        work = self.start()
+        if work is not None:
+            work.wait()
+        return self.finish()
