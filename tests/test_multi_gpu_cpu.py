@@ -39,6 +39,19 @@ def _worker(rank, world, port, res_w, res_h, strip_rows, out_path):
         assert px.size == sg.counts[rank]
         sg.local[: px.size] = torch.from_numpy(px.view(np.int32).copy())
         full = sg.exchange()
+        # the pipelined form bench.py uses: two buffer sets, gathers in flight while the next frame is produced, finish() later
+        sets = [StripGather(res_w, res_h, strip_rows, world, rank, torch.device("cpu")) for _ in range(2)]
+        works = []
+        for k, s2 in enumerate(sets):
+            s2.local[: px.size] = torch.from_numpy(px.view(np.int32).copy()) + k      # frame k = the frame with k added to every pixel
+            works.append(s2.start())
+        for k, s2 in enumerate(sets):
+            works[k].wait()
+            got = s2.finish()
+            if rank == 0:
+                assert torch.equal(got, full + k)
+            else:
+                assert got is None
         if rank == 0:
             np.save(out_path, full.numpy())
     finally:
