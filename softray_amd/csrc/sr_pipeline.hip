@@ -1378,8 +1378,11 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                 const float kmax = fmaxf(fmaxf(fabsf(P.x), fabsf(Q.x)), fabsf(T.x));
                 const float mc = dmax * (kU24 * (15.0f * cf.s0 + 16.0f * (kmax + fabsf(G0))) + 1e-9f);
                 float4* w = wc + lane * 5;
-                w[0] = make_float4(slab.n[0], slab.n[1], slab.n[2], N.y);
-                w[1] = W[0]; w[2] = W[1]; w[3] = W[2];
+                // (constant term first: it is the packed FMAs' addend, broadcast from the low register of an aligned pair)
+                w[0] = make_float4(N.y, slab.n[0], slab.n[1], slab.n[2]);
+                w[1] = make_float4(W[0].w, W[0].x, W[0].y, W[0].z);
+                w[2] = make_float4(W[1].w, W[1].x, W[1].y, W[1].z);
+                w[3] = make_float4(W[2].w, W[2].x, W[2].y, W[2].z);
                 // .y: margin of "inside every edge" (unreachable unless E' is definitely behind the plane);
                 // .z: margin of "outside an edge" (always reached when E' is definitely in front of the plane)
                 w[4] = make_float4(G0, G0 <= -cf.a0 ? mc : 1e30f, G0 >= cf.a0 ? -1e30f : mc, 0.0f);
@@ -1407,38 +1410,43 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
             __builtin_amdgcn_wave_barrier();
             n_recs += (uint32_t)nc;
             // ---- fp32 classification of every (sample, candidate) pair.  tblk > 0: BLOCKED; tall > 0: decided (BLOCKED or
-            //      MISS); bit k of unc[q]: pair (sample q, candidate k) is undecided.  bsum[q] > 0: some candidate blocked the
-            //      sample (dead samples keep running through the arithmetic: nothing they produce is looked at) ----
+            //      MISS); bit k of unc[q]: pair (sample q, candidate k) is undecided ----
             uint32_t unc[kPacketSlots] = {0u, 0u};
-            float bsum[kPacketSlots] = {-1.0f, -1.0f};
+            // (wave-uniform masks instead of per-lane running maxima: the bookkeeping of "still undecided" is scalar work)
+            const unsigned long long al0 = __ballot(alive[0]), al1 = __ballot(alive[1]);
+            unsigned long long blk0 = 0ull, blk1 = 0ull;                  // samples some candidate of this chunk blocks
             int k = 0;
-            unsigned long long am0 = 0ull, am1 = 0ull;                    // (wave-uniform) samples still undecided
+            unsigned long long am0 = 0ull, am1 = 0ull;                    // samples still undecided
             int na = 128;
             for (; k < nc && have; ++k) {
                 if (TAIL && !(k & 1) && na <= 64) break;                  // few samples left: the tail layout takes the rest of the chunk
                 const float4 A = wc[k * 5], B1 = wc[k * 5 + 1], B2 = wc[k * 5 + 2], B3 = wc[k * 5 + 3], F = wc[k * 5 + 4];
-                // packed over the lane's two samples (.x = sample lane, .y = sample lane + 64)
-                const f2 g1 = pk_fma(splat(A.x), OX, pk_fma(splat(A.y), OY, pk_fma(splat(A.z), OZ, splat(A.w))));
-                const f2 c1 = pk_fma(splat(B1.x), OX, pk_fma(splat(B1.y), OY, pk_fma(splat(B1.z), OZ, splat(B1.w))));
-                const f2 c2 = pk_fma(splat(B2.x), OX, pk_fma(splat(B2.y), OY, pk_fma(splat(B2.z), OZ, splat(B2.w))));
-                const f2 c3 = pk_fma(splat(B3.x), OX, pk_fma(splat(B3.y), OY, pk_fma(splat(B3.z), OZ, splat(B3.w))));
+                // packed over the lane's two samples (.x = sample lane, .y = sample lane + 64); records: (constant, x, y, z)
+                // value = x * OX + (y * OY + (z * OZ + constant)), the scalars broadcast by the FMAs' operand selects
+                const auto plane = [&](const float4& r) {
+                    const f2 cx = {r.x, r.y}, yz = {r.z, r.w};
+                    return pk_fma_hi(cx, OX, pk_fma_lo(yz, OY, pk_fma_hi_addlo(yz, OZ, cx)));
+                };
+                const f2 g1 = plane(A), c1 = plane(B1), c2 = plane(B2), c3 = plane(B3);
                 const f2 hb = pk_fma(UM, g1, splat(F.x));                 // G at u = umax_i: > 0 <=> the crossing comes earlier
                 const f2 cmin = {fminf(fminf(c1.x, c2.x), c3.x), fminf(fminf(c1.y, c2.y), c3.y)};
                 const f2 s3 = g1 - splat(glo), s1 = cmin - splat(F.y), s4 = hb - splat(hbm);
                 const f2 tm0 = splat(-F.z) - cmin, bfv = splat(-glo) - g1;
-#pragma unroll
-                for (int q = 0; q < kPacketSlots; ++q) {
-                    const float s3q = q ? s3.y : s3.x;
-                    const float tblk = fminf(fminf(q ? s1.y : s1.x, s3q), q ? s4.y : s4.x);
-                    const float tall = fmaxf(fmaxf(fminf(q ? tm0.y : tm0.x, s3q), q ? bfv.y : bfv.x), tblk);
-                    bsum[q] = fmaxf(bsum[q], tblk);
-                    unc[q] |= tall > 0.0f ? 0u : (1u << k);
-                }
-                if (STATS) n_cls += (alive[0] && !(bsum[0] > 0.0f) ? 1u : 0u) + (alive[1] && !(bsum[1] > 0.0f) ? 1u : 0u);
-                am0 = __ballot(alive[0] && !(bsum[0] > 0.0f)); am1 = __ballot(alive[1] && !(bsum[1] > 0.0f));
+                const float tblk0 = fminf(fminf(s1.x, s3.x), s4.x), tblk1 = fminf(fminf(s1.y, s3.y), s4.y);
+                const float tall0 = fmaxf(fmaxf(fminf(tm0.x, s3.x), bfv.x), tblk0), tall1 = fmaxf(fmaxf(fminf(tm0.y, s3.y), bfv.y), tblk1);
+                // (shifted in from the right: compare + add-with-carry; put into candidate order after the loop)
+                unc[0] = shift_in_not_positive(unc[0], tall0);
+                unc[1] = shift_in_not_positive(unc[1], tall1);
+                blk0 |= __ballot(tblk0 > 0.0f);
+                blk1 |= __ballot(tblk1 > 0.0f);
+                am0 = al0 & ~blk0; am1 = al1 & ~blk1;
+                if (STATS) n_cls += (uint32_t)((am0 >> lane) & 1ull) + (uint32_t)((am1 >> lane) & 1ull);
                 na = (int)__popcll(am0) + (int)__popcll(am1);
                 have = na != 0;
             }
+            if (k > 0) { unc[0] = __brev(unc[0]) >> (32 - k); unc[1] = __brev(unc[1]) >> (32 - k); }   // bit j = candidate j
+            // bsum[q] > 0: some candidate blocked the sample (dead samples ran through the arithmetic too: nothing they produced is looked at)
+            float bsum[kPacketSlots] = {((blk0 >> lane) & 1ull) != 0ull ? 1.0f : -1.0f, ((blk1 >> lane) & 1ull) != 0ull ? 1.0f : -1.0f};
             if (k == 0 && have) {                                         // (entered with few samples: later rounds, later chunks)
                 am0 = __ballot(alive[0]); am1 = __ballot(alive[1]);
                 na = (int)__popcll(am0) + (int)__popcll(am1);

@@ -248,6 +248,30 @@ __device__ bool brute_intersect(const Rec128* tris, int ntris, D3 s, D3 d, Hit& 
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { f2 r = {v, v}; return r; }
+// v_pk_fma_f32 with one half of a register pair broadcast to both lanes by the instruction's own operand selects (the compiler
+// copies an odd register into a fresh pair first when the scalar comes from the high half of a loaded vector):
+//   pk_fma_lo(P, b, c) = (P.x, P.x) * b + c      pk_fma_hi(P, b, c) = (P.y, P.y) * b + c
+//   pk_fma_hi_addlo(P, b, C) = (P.y, P.y) * b + (C.x, C.x)
+// bits = 2 * bits + (t > 0 ? 0 : 1): compare into the carry, add with carry (an undecided verdict -- also a NaN -- shifts in a one)
+__device__ __forceinline__ uint32_t shift_in_not_positive(uint32_t bits, float t) {
+    asm("v_cmp_nlt_f32 vcc, 0, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(t) : "vcc");
+    return bits;
+}
+__device__ __forceinline__ f2 pk_fma_lo(f2 P, f2 b, f2 c) {
+    f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(d) : "v"(P), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f2 pk_fma_hi(f2 P, f2 b, f2 c) {
+    f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(P), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f2 pk_fma_hi_addlo(f2 P, f2 b, f2 C) {
+    f2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(P), "v"(b), "v"(C));
+    return d;
+}
 
 // Slab test of both children of a node as packed FMAs (v_pk_fma_f32: two floats per issue slot).  Per axis
 // t = plane * inv + bias with bias = -origin * inv (walks that inflate the boxes add -+r * inv); the node's twelve
