@@ -1418,12 +1418,18 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
             int k = 0;
             unsigned long long am0 = 0ull, am1 = 0ull;                    // samples still undecided
             int na = 128;
+            // (the record of candidate k + 1 is requested before candidate k is worked on: an LDS round trip per candidate would
+            //  otherwise be waited for in full; the slot after the chunk's last record is readable LDS whose content is not used)
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4* wc4 = reinterpret_cast<const f4*>(wc);
+            f4 nA = wc4[0], nB1 = wc4[1], nB2 = wc4[2], nB3 = wc4[3], nF = wc4[4];
             for (; k < nc && have; ++k) {
                 if (TAIL && !(k & 1) && na <= 64) break;                  // few samples left: the tail layout takes the rest of the chunk
-                const float4 A = wc[k * 5], B1 = wc[k * 5 + 1], B2 = wc[k * 5 + 2], B3 = wc[k * 5 + 3], F = wc[k * 5 + 4];
+                const f4 A = nA, B1 = nB1, B2 = nB2, B3 = nB3, F = nF;
+                nA = wc4[k * 5 + 5]; nB1 = wc4[k * 5 + 6]; nB2 = wc4[k * 5 + 7]; nB3 = wc4[k * 5 + 8]; nF = wc4[k * 5 + 9];
                 // packed over the lane's two samples (.x = sample lane, .y = sample lane + 64); records: (constant, x, y, z)
                 // value = x * OX + (y * OY + (z * OZ + constant)), the scalars broadcast by the FMAs' operand selects
-                const auto plane = [&](const float4& r) {
+                const auto plane = [&](const f4& r) {
                     const f2 cx = {r.x, r.y}, yz = {r.z, r.w};
                     return pk_fma_hi(cx, OX, pk_fma_lo(yz, OY, pk_fma_hi_addlo(yz, OZ, cx)));
                 };
@@ -1443,6 +1449,9 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                 if (STATS) n_cls += (uint32_t)((am0 >> lane) & 1ull) + (uint32_t)((am1 >> lane) & 1ull);
                 na = (int)__popcll(am0) + (int)__popcll(am1);
                 have = na != 0;
+                // (the requested record must have arrived HERE, not at the top of the next iteration where the compiler would
+                //  otherwise move the request to)
+                asm volatile("" : "+v"(nA), "+v"(nB1), "+v"(nB2), "+v"(nB3), "+v"(nF));
             }
             if (k > 0) { unc[0] = __brev(unc[0]) >> (32 - k); unc[1] = __brev(unc[1]) >> (32 - k); }   // bit j = candidate j
             // bsum[q] > 0: some candidate blocked the sample (dead samples ran through the arithmetic too: nothing they produced is looked at)
