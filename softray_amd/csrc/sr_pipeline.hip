@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                                                unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
                                                uint32_t* __restrict__ samples, unsigned int* __restrict__ work_count,
                                                unsigned int* __restrict__ work_list, unsigned long long* stats, unsigned int* dbg) {
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x;
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
     const unsigned int total = min(*hit_count, count_cap);
     const unsigned int slot_i = blockIdx.x * 256u + (unsigned)tid;       // list slot: the hit itself, or an entry of index_list
@@ -516,7 +516,6 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
         float nu = 1.0f;               // upper bound of u (distance from the surface end) inside the current subtree
         // while-while: walk inner nodes until this lane owns a pending leaf, then run the (per-triangle) slab filters
         int32_t leafA = -1, leafB = -1;            // pending leaves: first record | count << kLeafShift
-        float laA = 0, lbA = 0, laB = 0, lbB = 0;  // their u-intervals
         for (;;) {
             while (ni >= 0 && leafA < 0) {
                 const BvhNode n = sc.bnodes[ni];
@@ -536,10 +535,10 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
                 const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
                 if (l0 && l1) {
                     const bool first0 = a0 <= a1;
-                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << kLeafShift); laA = first0 ? a0 : a1; lbA = first0 ? b0 : b1;
-                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << kLeafShift); laB = first0 ? a1 : a0; lbB = first0 ? b1 : b0;
-                } else if (l0) { leafA = n.c0 | (n.n0 << kLeafShift); laA = a0; lbA = b0; }
-                else if (l1) { leafA = n.c1 | (n.n1 << kLeafShift); laA = a1; lbA = b1; }
+                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << kLeafShift);
+                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << kLeafShift);
+                } else if (l0) leafA = n.c0 | (n.n0 << kLeafShift);
+                else if (l1) leafA = n.c1 | (n.n1 << kLeafShift);
                 const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
                 if (i0 && i1) {
                     const bool first0 = a0 <= a1;                          // the child nearest to the surface point first
@@ -559,7 +558,7 @@ __global__ __launch_bounds__(256) void k_shaft(DevScene sc, FrameConst fc, const
             if (leafA < 0) break;
             while (leafA >= 0 && !truncated && !umbra) {
                 const int first = leafA & kLeafMask, cnt = (leafA >> kLeafShift) & 15;
-                leafA = leafB; laA = laB; lbA = lbB;
+                leafA = leafB;
                 leafB = -1;
                 leaves++;
                 slabs += (uint32_t)cnt;
