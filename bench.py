@@ -31,18 +31,38 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
+# numpy / torch / the product library are imported by _imports(), AFTER the fan-out decision in main(): the parent of a plain
+# `python bench.py --gpus N` only spawns torch.distributed.run as a child process and must never initialise the GPU itself
+np = torch = dist = sa = R = StripGather = None
 
-import softray_amd as sa
-from softray_amd import renderer as R
-from softray_amd.distributed import StripGather
+
+def _imports():
+    global np, torch, dist, sa, R, StripGather
+    import numpy as np_
+    import torch as torch_
+    import torch.distributed as dist_
+    import softray_amd as sa_
+    from softray_amd import renderer as R_
+    from softray_amd.distributed import StripGather as SG_
+    np, torch, dist, sa, R, StripGather = np_, torch_, dist_, sa_, R_, SG_
+
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 VALU_PEAK_LANE_OPS = 256 * 4 * 16 * 2.4e9     # CUs x SIMDs x lanes per cycle x clock: 39.3 T lane-instructions / s (an FMA counts once)
 S_NODE, S_TRI, S_SLAB, S_PIX = 64, 128, 64, 4  # bytes: BVH node, FP64 triangle record, fp32 TriSlab / CamCone record, pixel store
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02_final")
+
+
+def profile_dir(args):
+    """committed rocprofv3 summaries of this workload (the newest round that has them)"""
+    if args.tris == 10000000:
+        cands = [os.path.join("r03_c5", "bounces" if args.bounces > 0 else "shadows")]
+    else:
+        cands = ["r03_final", "r02_final"]
+    for c in cands:
+        d = os.path.join(ROOT, "profiles", c)
+        if os.path.exists(os.path.join(d, "sq_counters_summary.csv")):
+            return d
+    return os.path.join(ROOT, "profiles", cands[0])
 
 
 def make_frame(args, strips=None):
@@ -100,11 +120,12 @@ def host_cores():
     return cores
 
 
-def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=22.0):
+def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=30.0):
     """The reference's CPU path = the C++ oracle (statement-level restatement; real C# cannot be built here), reference tree
-    depth 15 / 25 per leaf, row-block threads like Renderer.cs:1659-1670, timed on a centred band of rows of the SAME frame
-    (bounded sample) at threads = all host cores (the headline `value`) and threads = 4 (rayTraceConcurrency's default,
-    Renderer.cs:82), as SURVEY 8d / BASELINE.md 3 ask."""
+    depth 15 / 25 per leaf, row-block threads like Renderer.cs:1659-1670, timed on a CENTRED SQUARE CROP of the SAME frame
+    (rows and columns windowed, same rays; BASELINE.md 3: 256^2 of the 4096^2 frame, smaller when the host's cores would need
+    more than the budget) at threads = all host cores (the headline `value`) and at threads = 4 (rayTraceConcurrency's default,
+    Renderer.cs:82) on a 64^2 crop.  The round-2 sample -- a band of whole centre rows -- is kept as `sample_rows`."""
     from oracle import oracle_py as orc                              # the only place bench.py touches oracle/
     cores = host_cores()
     o = orc.Scene()
@@ -116,23 +137,32 @@ def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=22.0):
     f.trace_mode = orc.MODE_REF_TREE
     mid = args.res // 2
     scratch = np.zeros(args.res * args.res, dtype=np.int32)
+    spp2 = args.spp * args.spp
 
-    def timed(threads, budget):
-        rows, total_rows, total_s = 1, 0, 0.0
-        while True:                                                  # grow the band until ~budget of CPU work
-            f.start_row, f.end_row = mid - rows // 2, mid - rows // 2 + rows - 1
-            t0 = time.time()
-            o.render(f, threads=threads, out=scratch)
-            dt = time.time() - t0
-            total_rows, total_s = rows, dt
-            if dt >= budget * 0.5 or rows >= args.res:
-                break
-            rows = min(args.res, max(rows * 2, int(rows * budget / max(dt, 1e-3) * 0.8)))
-        rays = total_rows * args.res * args.spp * args.spp
-        return rays / total_s / 1e6, total_rows, rays, total_s
+    def crop(side, threads):
+        side = min(side, args.res)
+        a = mid - side // 2
+        f.start_row, f.end_row = a, a + side - 1
+        t0 = time.time()
+        o.render(f, threads=threads, out=scratch, cols=(a, a + side))
+        dt = time.time() - t0
+        return side * side * spp2 / dt / 1e6, side * side * spp2, dt
 
-    v_all, rows_all, rays_all, s_all = timed(cores, budget_s * 0.55)
-    v_4, rows_4, rays_4, s_4 = timed(min(4, cores), budget_s * 0.45)
+    # all cores: 64^2 first (also the estimate for the larger crops), then the largest of 256^2 / 128^2 the budget allows
+    v_all, rays_all, s_all = crop(64, cores)
+    side_all = 64
+    for side in (256, 128):
+        if side <= args.res and s_all * (side / 64.0) ** 2 <= budget_s:
+            v_all, rays_all, s_all = crop(side, cores)
+            side_all = side
+            break
+    v_4, rays_4, s_4 = crop(64, min(4, cores))
+    # the round-2 sample: whole rows through the centre of the frame (the most expensive rows: every pixel hit and shadowed)
+    f.start_row, f.end_row = mid - 1, mid
+    t0 = time.time()
+    o.render(f, threads=cores, out=scratch)
+    s_rows = time.time() - t0
+    rays_rows = 2 * args.res * spp2
     # a C# toolchain on the GPU box would let the genuine reference be timed: probe, never assume
     csharp = [t for t in ("dotnet", "mono", "mcs", "csc") if shutil.which(t)]
     cpu_model = ""
@@ -144,18 +174,21 @@ def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=22.0):
     except Exception:
         pass
     return {"value": v_all, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d centred rows x %d cols of the same %dx%d frame (%d primary rays, %.1f s); C++ restatement of "
+            "sample": "centred %dx%d crop (rows and columns windowed) of the same %dx%d frame (%d primary rays, %.1f s); C++ restatement of "
                       "the reference algorithm (reference tree 15/25, row-block threads, g++ -O2 -ffp-contract=off) -- real C# unavailable; "
-                      "tree build %.1f s excluded" % (rows_all, args.res, args.res, args.res, rays_all, s_all, build_s),
-            "threads_4": {"value": v_4, "threads": min(4, cores), "sample": "%d centred rows (%d primary rays, %.1f s)" % (rows_4, rays_4, s_4),
+                      "tree build %.1f s excluded" % (side_all, side_all, args.res, args.res, rays_all, s_all, build_s),
+            "threads_4": {"value": v_4, "threads": min(4, cores), "sample": "centred 64x64 crop (%d primary rays, %.1f s)" % (rays_4, s_4),
                           "note": "rayTraceConcurrency's default (Renderer.cs:82)"},
+            "sample_rows": {"value": rays_rows / s_rows / 1e6, "threads": cores,
+                            "sample": "2 whole centre rows x %d cols (%d primary rays, %.1f s): the round-2 sample, biased low (every pixel of "
+                                      "these rows is hit and shadowed; a third of the frame is background)" % (args.res, rays_rows, s_rows)},
             "cpu_model": cpu_model,
             "csharp_toolchain_on_this_box": csharp or None,
             "csharp_note": ("found %s: the genuine C# reference could be built here, but its sources do not travel to the GPU box" % csharp) if csharp
                            else "no dotnet / mono / mcs / csc on this box: the number is the C++ restatement of the reference algorithm"}
 
 
-def committed_profile():
+def committed_profile(PROFILE_DIR):
     """SQ counters / HBM traffic of this workload from the rocprofv3 passes committed under profiles/ (live PMC needs rocprofv3)."""
     out = {"issue": None, "traffic": {}}
     import csv
@@ -213,7 +246,29 @@ def main():
     ap.add_argument("--prelude-s", type=float, default=2.0, help="untimed seconds of continuous frames before the timed region (lets GPU-busy samplers see the GPU phase)")
     ap.add_argument("--verify", action="store_true", help="after timing: rank 0 re-renders the whole frame alone and compares it with the one that arrived on the host")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1 verifies the gathered frame against a single-GPU render by default; this turns it off")
+    ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks a plain `--gpus N` run spawns (0 = pick a free one)")
     args = ap.parse_args()
+
+    # ---- plain `python bench.py --gpus N` (no launcher): become the launcher.  BEFORE anything touches the GPU this process starts
+    #      `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD (never exec: see the environment notes) and
+    #      relays its output -- rank 0's JSON line included -- and its exit code ----
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.in_library:
+        import socket
+        import subprocess
+        port = args.master_port
+        if port <= 0:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "4")
+        sys.exit(subprocess.call(cmd, env=env))
+    _imports()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -355,6 +410,59 @@ def main():
                        "readback": "every frame copied to pinned host memory inside the timed region (the copy of frame k overlaps frame k+1)"},
             "build_s": build_s,
         }
+        if n_gpus > 1:
+            out["frame_crc"] = int(np.bitwise_xor.reduce(last_host_frame.view(np.uint32)))
+
+    if world > 1:
+        # ---- what a reader needs to cross-check the N > 1 line against N = 1 (all untimed, after the timed region): who took
+        #      part, every rank's own render time for its strips, and the three steps that follow the render on rank 0 ----
+        for p in pending:
+            if p is not None:
+                p.wait()
+        torch.cuda.synchronize(dev)
+        reps = 3
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            g.render_device(frame, sg[0].local.data_ptr(), stream.cuda_stream)
+        torch.cuda.synchronize(dev)
+        my_ms = (time.perf_counter() - t1) / reps * 1e3
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "device": "cuda:%d" % local_rank, "name": props.name, "render_ms": my_ms,
+                "rows": len(sg[0].rows[rank]), "pid": os.getpid()}
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+
+        def wall(fn):                                                # max over ranks of the wall time of fn() with the device drained
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+            t = time.perf_counter()
+            fn()
+            torch.cuda.synchronize(dev)
+            v = torch.tensor([(time.perf_counter() - t) * 1e3], dtype=torch.float64, device=dev)
+            dist.all_reduce(v, op=dist.ReduceOp.MAX)
+            return float(v.item())
+
+        def gather_only():
+            w = sg[0].start()
+            if w is not None:
+                w.wait()
+        gather_only()                                                # (once untimed)
+        gather_ms = min(wall(gather_only) for _ in range(reps))
+        deint_ms = min(wall(lambda: sg[0].finish()) for _ in range(reps))
+        rb_ms = min(wall((lambda: host[0].copy_(surfaces[0].view(-1))) if rank == 0 else (lambda: None)) for _ in range(reps))
+        if rank == 0:
+            out["multi_gpu"] = {
+                "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else None,
+                "world_size": dist.get_world_size(), "visible_devices": ndev,
+                "distinct_devices": len({(e["device"]) for e in everyone}),
+                "ranks": everyone,
+                "render_ms_max": max(e["render_ms"] for e in everyone), "render_ms_min": min(e["render_ms"] for e in everyone),
+                "gather_ms": gather_ms, "deinterleave_ms": deint_ms, "readback_ms": rb_ms,
+                "bytes_gathered_per_rank": int(sg[0].maxc) * 4,
+                "note": "per-rank render_ms = that rank's strips alone (device drained before and after, %d frames); gather / de-interleave / read-back = "
+                        "each step alone, max over ranks, best of %d; in the timed region they overlap the next frame's rendering" % (reps, reps),
+            }
 
     extras = world == 1 and not in_library and not args.no_extras
     if extras:
@@ -404,26 +512,58 @@ def main():
         #   k_shaft (packet walk)    per hit point 64 B queue record + 4 B count; per WAVE 64 B/node + 64 B/TriSlab; 4 B per list entry
         #   k_shadow (k_shadow_cls)  per hit point 64 B + 4 B + 8 B pixel RMW; per candidate 4 B list entry + 64 B TriSlab
         pkt_nodes, pkt_slabs = rs[6] - rs[14], rs[10] - rs[15]
+        bvh_nodes = g.bvh_stats()[1] if args.mode == "bvh" else 0
         algo = {
             "k_primary": S_PIX * npix + rs[2] * S_NODE + rs[1] * S_SLAB + rs[3] * S_TRI + 64.0 * rs[11],
             "k_shaft": rs[11] * (64.0 + 4.0) + pkt_nodes * S_NODE + pkt_slabs * S_SLAB + rs[8] * 4.0,
-            "k_shaft_round2": rs[14] * S_NODE + rs[15] * S_SLAB,
+            # one wave per hit point, every lane of a pass fetches its own node / TriSlab: the same records are touched again and again by
+            # different hit points, but one launch need not move a record more than once -- capped at the arrays' sizes
+            "k_shaft_round2": min(rs[14] * S_NODE + rs[15] * S_SLAB, float(bvh_nodes * S_NODE + args.tris * S_SLAB)),
             "k_shadow": rs[9] * (64.0 + 4.0 + 8.0) + rs[8] * ((S_TRI if args.exact_shadow_tests else S_SLAB) + 4.0),
+            # incoherent rays, one per lane: 4 B ray id + 8 B mask RMW per shadow ray, 2 x 64 B queue records + 5 B level colour per mirror
+            # ray; every LANE fetches its own 64 B nodes and 128 B FP64 records
+            "k_shadow_fallback": rs[16] * 12.0 + rs[18] * S_NODE + rs[17] * S_TRI,
+            "k_bounce": rs[20] * (2 * 64.0 + 5.0) + rs[22] * S_NODE + rs[21] * S_TRI,
         }
         dom = max(kt.items(), key=lambda kv: kv[1][0]) if kt else ("none", (float("nan"), 0))
         dom_name, dom_ms = dom[0], dom[1][0]
         algo_bytes = algo.get(dom_name, float("nan"))
         achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms == dom_ms and dom_ms > 0 else float("nan")
-        prof = committed_profile()
-        tkey = "%s_%d_%d_%d" % (args.mode, args.tris, args.res, args.shadows)
+        prof = committed_profile(profile_dir(args))
+        tkey = "%s_%d_%d_%d" % (args.mode, args.tris, args.res, args.shadows) + ("_b%d" % args.bounces if args.bounces > 0 else "")
         traffic = (prof["traffic"].get(tkey) or {}).get(dom_name)
         prof_kernels = (prof["issue"] or {}).get("kernels") or {}
-        prof_name = {"k_shaft": "k_shaft_pkt", "k_shadow": "k_shadow_cls"}.get(dom_name, dom_name)
+        prof_name = {"k_shaft": "k_shaft_pkt", "k_shadow": "k_shadow_cls", "k_shadow_fallback": "k_shadow_rays", "k_shaft_round2": "k_shaft"}.get(dom_name, dom_name)
         issue_achieved = prof_kernels.get(prof_name, {}).get("useful_lane_ops_per_s")
+        # ---- measured copy bandwidth of THIS device ("use the measured number as the denominator and state both"): a 1 GiB
+        #      device-to-device copy of float4 elements, best of 5 ----
+        peak_measured = None
+        try:
+            src = torch.empty(1 << 26, 4, dtype=torch.float32, device=dev).normal_()
+            dst = torch.empty_like(src)
+            dst.copy_(src)
+            best = float("inf")
+            for _ in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(stream)
+                dst.copy_(src)
+                b.record(stream)
+                b.synchronize()
+                best = min(best, a.elapsed_time(b))
+            peak_measured = 2.0 * src.numel() * 4 / (best * 1e-3) / 1e9
+            del src, dst
+        except Exception:
+            pass
+        # compulsory traffic: every scene byte once + every pixel once, per primary ray
+        scene_bytes = args.tris * (S_TRI + 2 * S_SLAB) + bvh_nodes * S_NODE       # FP64 records (leaf order), TriSlab + CamCone records, nodes
+        compulsory = (scene_bytes + 4.0 * npix) / primary_rays
         out.update({
             "rays": {"primary": rs[0], "shadow": rs[4], "primary_plus_shadow_Mrays_per_s": (rs[0] + rs[4]) / (ms_per_step * 1e-3) / 1e6},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS if achieved == achieved else None, "traffic": traffic,
+                         "peak_measured": peak_measured, "frac_of_peak_measured": (achieved / peak_measured) if (peak_measured and achieved == achieved) else None,
+                         "compulsory_bytes_per_ray": compulsory, "scene_bytes": scene_bytes,
+                         "compulsory_GBs_at_this_rate": compulsory * primary_rays / (ms_per_step * 1e-3) / 1e9,
                          "kernel": dom_name, "kernel_ms_per_launch": dom_ms, "launches_timed": dom[1][1], "algorithmic_bytes_per_launch": algo_bytes,
                          "all_kernels_ms_per_launch": {k: v[0] for k, v in kt.items()},
                          "all_kernels_algorithmic_GBs": {k: algo[k] / (v[0] * 1e-3) / 1e9 for k, v in kt.items() if k in algo and v[0] > 0},
@@ -477,7 +617,7 @@ def main():
         }
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, v9, argb, bmin, bmax)
-    if args.verify and rank == 0:
+    if (args.verify or (n_gpus > 1 and not args.no_verify)) and rank == 0:
         ref_scene = g
         if in_library:
             ref_scene = sa.GpuScene(0)

@@ -85,7 +85,7 @@ namespace Engine3D.Hip
         public static string LastError() { return Marshal.PtrToStringAnsi(sr_last_error()); }
 
         public const int SR_ERR_INVALID_ARG = -1, SR_ERR_OUT_OF_RANGE = -2, SR_ERR_NO_MODEL = -3, SR_ERR_FORMAT = -8;
-        public const int AbiVersion = 3;
+        public const int AbiVersion = 4;
 
         /// <param name="renderCall">true only for sr_render: Render() without a model draws nothing and returns (Renderer.cs:736-739)</param>
         public static void Check(int rc, bool renderCall = false)

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 3
+#define SR_ABI_VERSION 4
+#define SR_STATS_COUNT 24   /* entries of the ray-statistics array (sr_last_ray_stats, sr_render_device's d_stats) */
 
 enum {
     SR_OK                 =  0,
@@ -214,7 +215,7 @@ int  sr_reset_shadow_cache(sr_scene*);
  * work is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream) without host sync. */
 /* Ordering: the work is enqueued behind everything already on `hip_stream` and `hip_stream` continues only after it; a
  * shadowed frame is internally forked onto two library-owned streams (event fork / join), see SR_F_NO_SPLIT. */
-int  sr_render_device(sr_scene*, const sr_frame*, void* d_pixels, void* hip_stream, uint64_t* d_stats /* device uint64[16] (see sr_last_ray_stats) or NULL */);
+int  sr_render_device(sr_scene*, const sr_frame*, void* d_pixels, void* hip_stream, uint64_t* d_stats /* device uint64[SR_STATS_COUNT] (see sr_last_ray_stats) or NULL */);
 /* number of int32 pixels sr_render writes for this frame (W*H, or the compact strip size) */
 int64_t sr_frame_pixel_count(const sr_frame*);
 
@@ -264,9 +265,10 @@ int  sr_kernel_times(sr_scene*, sr_kernel_time* out, int32_t cap);
  * walks' nodes / leaves; [8] triangle records staged through LDS by k_shadow_test, [9] hit points it processed,
  * [10] fp32 slab records read by k_shaft, [11] hit points it walked, [12] (sample, triangle) pairs k_shadow_test classified
  * in fp32, [13] pairs it had to decide with the exact FP64 test, [14] / [15] the part of [6] / [10] that came from private per-lane
- * shaft walks (later rounds) rather than from the packet walk.  These are the counters the roofline's
- * algorithmic bytes are priced from (DESIGN.md "Measurement"). */
-int  sr_last_ray_stats(const sr_scene*, uint64_t out[16]);
+ * shaft walks (later rounds) rather than from the packet walk; [16..19] the exact fallback's any-hit rays on their own {rays,
+ * FP64 triangle records tested, nodes fetched per lane, leaves} (also contained in [4..7]); [20..23] the same for the mirror
+ * rays of the bounce pipeline.  These are the counters the roofline's algorithmic bytes are priced from (DESIGN.md "Measurement"). */
+int  sr_last_ray_stats(const sr_scene*, uint64_t out[SR_STATS_COUNT]);
 
 /* Seeded synthetic triangle soup = SpatialSubdivisionTests.MakeRandomTriangles
  * (Engine3D-Tests/Raytrace/SpatialSubdivisionTests.cs:397-411) driven by the System.Random port: per triangle

@@ -80,6 +80,7 @@ def lib():
         L.orc_scene_tree_stats.argtypes = [vp, vp]
         L.orc_scene_reset_shadow_cache.argtypes = [vp]
         L.orc_render.restype = i32; L.orc_render.argtypes = [vp, vp, vp, vp, i32]
+        L.orc_render_window.restype = i32; L.orc_render_window.argtypes = [vp, vp, vp, vp, i32, i32, i32]
         L.orc_shade_points.restype = i32
         L.orc_shade_points.argtypes = [vp, i64, vp, vp, vp, vp, i32]
         L.orc_trace.restype = i32
@@ -209,7 +210,8 @@ class Scene:
         lib().orc_scene_tree_stats(self._h, _p(out))
         return tuple(int(x) for x in out)
 
-    def render(self, frame, threads=1, out=None):
+    def render(self, frame, threads=1, out=None, cols=None):
+        """cols = (begin, end): only those columns of the frame's rows are drawn (orc_render_window), the rest of `out` is untouched."""
         f = frame
         if f.strip_count > 0:
             rows = [r for r in range(max(0, f.start_row), min(f.height - 1, f.end_row) + 1)
@@ -219,7 +221,10 @@ class Scene:
             n = f.width * f.height
         pixels = out if out is not None else np.zeros(n, dtype=np.int32)
         stats = np.zeros(4, dtype=np.uint64)
-        rc = lib().orc_render(self._h, C.byref(f), _p(pixels), _p(stats), threads)
+        if cols is not None:
+            rc = lib().orc_render_window(self._h, C.byref(f), _p(pixels), _p(stats), threads, int(cols[0]), int(cols[1]))
+        else:
+            rc = lib().orc_render(self._h, C.byref(f), _p(pixels), _p(stats), threads)
         if rc != 0:
             raise RuntimeError("orc_render failed: %d" % rc)
         return pixels.view(np.uint32), stats

@@ -1031,7 +1031,21 @@ int orc_shade_points(const orc_frame* f, int64_t n, const double* pos, const dou
     return 0;
 }
 
+static int RenderColumns(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t stats[4], int32_t threads, int colBegin, int colEnd);
+
 int orc_render(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t stats[4], int32_t threads) {
+    return RenderColumns(s, f, pixels, stats, threads, 0, f->width);
+}
+
+/* the same frame restricted to columns [col_begin, col_end): every pixel it draws is the pixel orc_render draws there (pixels
+ * are independent, Renderer.cs:1690: RaytraceBlock takes left / sizeX); used for the CPU baseline's centred crop only */
+int orc_render_window(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t stats[4], int32_t threads, int32_t col_begin, int32_t col_end) {
+    if (col_begin < 0 || col_end > f->width || col_begin >= col_end) return -8;
+    if (f->flags & ORC_F_STATIC_SHADOWS) return -7;              /* the static cache's fill order is defined over whole rows */
+    return RenderColumns(s, f, pixels, stats, threads, col_begin, col_end);
+}
+
+static int RenderColumns(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t stats[4], int32_t threads, int colBegin, int colEnd) {
     if (!s->haveBox || s->tris.empty()) return -3;               /* no model pinned: Renderer.cs:736-739 */
     if (f->trace_mode == ORC_MODE_REF_TREE && !s->haveTree) return -4;
     if (f->sub_pixel_res < 1) return -5;
@@ -1086,7 +1100,7 @@ int orc_render(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t
     /* work items = 64-pixel chunks of a row (the reference fans out row BLOCKS, Renderer.cs:1659-1670; pixels are
      * independent, so the partition does not change any pixel) */
     const int chunk = 64;
-    const size_t chunksPerRow = (size_t)(f->width + chunk - 1) / chunk;
+    const size_t chunksPerRow = (size_t)(colEnd - colBegin + chunk - 1) / chunk;
     std::atomic<size_t> nextItem{0};
     std::vector<Counters> prim(nthreads), sec(nthreads);
     std::vector<int64_t> rays(nthreads, 0);
@@ -1095,7 +1109,7 @@ int orc_render(const orc_scene* s, const orc_frame* f, int32_t* pixels, uint64_t
             size_t item = nextItem.fetch_add(1);
             if (item >= rows.size() * chunksPerRow) break;
             size_t i = item / chunksPerRow;
-            int c0 = (int)(item % chunksPerRow) * chunk, c1 = std::min(f->width, c0 + chunk);
+            int c0 = colBegin + (int)(item % chunksPerRow) * chunk, c1 = std::min(colEnd, c0 + chunk);
             int row = rows[i];
             int32_t* dst = (f->strip_count > 0) ? pixels + (size_t)i * f->width : pixels + (size_t)row * f->width;
             for (int col = c0; col < c1; col++)

@@ -102,6 +102,10 @@ void orc_scene_reset_shadow_cache(orc_scene*);   /* a new Renderer / ShadowMetho
  * strip_count>0).  stats = rays fired, geometry tests, node visits, leaf visits (primary rays;
  * deterministic sums, not the reference's racy per-block counters).  threads<=0 => 1. */
 int  orc_render(const orc_scene*, const orc_frame*, int32_t* pixels, uint64_t stats[4], int32_t threads);
+/* orc_render restricted to columns [col_begin, col_end) of the frame's rows (the other pixels are left untouched): the CPU
+ * baseline's centred crop (bench.py).  Test infrastructure only, like everything in oracle/. */
+int  orc_render_window(const orc_scene*, const orc_frame*, int32_t* pixels, uint64_t stats[4], int32_t threads,
+                       int32_t col_begin, int32_t col_end);
 
 /* ShadingMethod.IntersectRay's colour step (ShadingMethod.cs:36-68, CalcLighting :110-177) for n recorded intersections:
  * out[i] = ModulatePackedColor(color[i], (byte)(255 * intensity(pos[i], normal[i]))) with the frame's light / transform. */

@@ -1,11 +1,12 @@
 """Copy the judged summaries of a gpu_profile.sh / gpu_sq_counters.sh / gpu_lane_util.sh run from gpurun_out/ into
-profiles/<name>/ and refresh profiles/hbm_traffic.json.  usage: python scripts/collect_profile.py r02 profiles/r02_final
+profiles/<name>/ and refresh profiles/hbm_traffic.json.  usage: python scripts/collect_profile.py r02 profiles/r02_final [workload key]
 
 All three scripts run `bench.py --no-split` (the frame as ONE pipeline: no two kernels share the GPU), so a kernel's row is
 the launch the roofline talks about.  Launches of the STATS instantiations (one untimed counter pass) are left out."""
 import collections, csv, json, os, shutil, sys
 
 tag, dst = sys.argv[1], sys.argv[2]
+workload = sys.argv[3] if len(sys.argv) > 3 else "bvh_1000000_4096_100"     # key of profiles/hbm_traffic.json: mode_tris_res_shadows[_bN]
 src = "gpurun_out/prof_%s" % tag
 sq = "gpurun_out/sq_%s" % tag
 os.makedirs(dst, exist_ok=True)
@@ -61,13 +62,20 @@ per_launch = {k: traffic[k] / max(1, len(launches[k])) for k in traffic}
 table = {"k_primary": per_launch.get("k_primary"), "k_shaft": per_launch.get("k_shaft_pkt"), "k_shaft_round2": per_launch.get("k_shaft"),
          "k_shadow": (2.0 * per_launch["k_shadow_cls"]) if "k_shadow_cls" in per_launch else None,
          "k_shadow_fallback": sum(per_launch.get(k, 0.0) for k in ("k_fb_expand", "k_shadow_rays", "k_fb_resolve", "k_shadow_wave")),
+         "k_bounce_per_level": per_launch.get("k_bounce"), "k_bounce": (traffic.get("k_bounce", 0.0) + traffic.get("k_fold", 0.0)) / max(1, len(launches.get("k_fold", ()))) if "k_bounce" in traffic else None,
          "_launches_counted": {k: len(v) for k, v in launches.items()}}
-hb = {"bvh_1000000_4096_100": table,
-      "_how": "HBM bytes per LAUNCH of each kernel = sum over its timed launches of (2*FETCH_SIZE + WRITE_SIZE)*1024 / number of launches, rocprofv3 --pmc "
-              "FETCH_SIZE / --pmc WRITE_SIZE in separate passes (%s), FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane loads on gfx950; "
+hb = {}
+if os.path.exists("profiles/hbm_traffic.json"):
+    try:
+        hb = json.load(open("profiles/hbm_traffic.json"))
+    except Exception:
+        hb = {}
+hb[workload] = table
+hb["_how"] = ("HBM bytes per LAUNCH of each kernel = sum over its timed launches of (2*FETCH_SIZE + WRITE_SIZE)*1024 / number of launches, rocprofv3 --pmc "
+              "FETCH_SIZE / --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane loads on gfx950; "
               "bench.py --no-split: one launch per frame of k_primary / k_shaft (packet walk, round 1) / k_shaft_round2; `k_shadow` = the two launches of "
-              "k_shadow_cls of a frame (rounds 1 and 2) together" % dst,
-      "_command": "bash scripts/gpu_profile.sh %s   (bench.py default workload, --steps 2 --warmup 1 --no-split)" % tag}
+              "k_shadow_cls of a frame (rounds 1 and 2) together; `k_bounce` = all levels' k_bounce launches + k_fold of one frame (what the K_BOUNCE event pair brackets)")
+hb.setdefault("_sources", {})[workload] = {"dir": dst, "command": "bash scripts/gpu_profile.sh %s ...   (bench.py --steps 2 --warmup 1 --no-split)" % tag}
 json.dump(hb, open("profiles/hbm_traffic.json", "w"), indent=1)
 
 # ---- SQ issue / wait summary per kernel (timed launches)

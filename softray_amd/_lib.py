@@ -76,7 +76,7 @@ def build(force=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "softray.h")]
     newest = max(os.path.getmtime(p) for p in srcs)
     if force or not os.path.exists(LIB_PATH) or os.path.getmtime(LIB_PATH) < newest:
-        subprocess.check_call(["make", "-C", CSRC, "-s"])
+        subprocess.check_call(["make", "-C", CSRC, "-s", "-j%d" % max(1, min(8, os.cpu_count() or 1))])
     return LIB_PATH
 
 

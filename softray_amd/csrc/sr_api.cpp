@@ -120,7 +120,7 @@ struct sr_scene {
     // kernel timing: one HIP event pair per launch, accumulated until sr_reset_kernel_times()
     std::vector<hipEvent_t> ev[sr::K_COUNT];       // [2*i] start, [2*i+1] stop
     int  ev_used[sr::K_COUNT] = {};
-    uint64_t last_stats[16] = {};
+    uint64_t last_stats[SR_STATS_COUNT] = {};
     int64_t dbg[SR_DBG_COUNT];             // sr_debug_set hooks, -1 = default (never read from the environment)
     sr_scene() { for (auto& d : dbg) d = -1; }
 };
@@ -865,8 +865,8 @@ static int multi_render(sr_scene* m, const sr_frame* f, int32_t* host_pixels, vo
         SR_HIP(q->d_pixels.reserve((size_t)count * 4));
         unsigned long long* ds = nullptr;
         if (stats4) {
-            SR_HIP(q->d_stats.reserve(16 * sizeof(uint64_t)));
-            SR_HIP(hipMemsetAsync(q->d_stats.p, 0, 16 * sizeof(uint64_t), nullptr));
+            SR_HIP(q->d_stats.reserve(SR_STATS_COUNT * sizeof(uint64_t)));
+            SR_HIP(hipMemsetAsync(q->d_stats.p, 0, SR_STATS_COUNT * sizeof(uint64_t), nullptr));
             ds = (unsigned long long*)q->d_stats.p;
         }
         if ((rc = render_common(q, &fg[g], (uint32_t*)q->d_pixels.p, nullptr, ds))) return rc;
@@ -893,14 +893,14 @@ static int multi_render(sr_scene* m, const sr_frame* f, int32_t* host_pixels, vo
         SR_HIP(hipEventRecord(m->multi_done, user_stream));
     }
     if (host_pixels) {
-        for (int k = 0; k < 16; ++k) m->last_stats[k] = 0;
+        for (int k = 0; k < SR_STATS_COUNT; ++k) m->last_stats[k] = 0;
         for (int g = 0; g < n; ++g) {
             sr_scene* q = m->parts[g];
             if ((rc = use_device(q))) return rc;
             SR_HIP(hipStreamSynchronize(nullptr));
             if (stats4 && sr_frame_pixel_count(&fg[g]) > 0) {
-                SR_HIP(hipMemcpy(q->last_stats, q->d_stats.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
-                for (int k = 0; k < 16; ++k) m->last_stats[k] += q->last_stats[k];
+                SR_HIP(hipMemcpy(q->last_stats, q->d_stats.p, SR_STATS_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
+                for (int k = 0; k < SR_STATS_COUNT; ++k) m->last_stats[k] += q->last_stats[k];
             }
         }
         if (stats4) std::memcpy(stats4, m->last_stats, 4 * sizeof(uint64_t));
@@ -919,7 +919,7 @@ int sr_render_device(sr_scene* s, const sr_frame* f, void* d_pixels, void* hip_s
     if ((rc = check_mode(s, f->trace_mode))) return rc;
     if ((rc = use_device(s))) return rc;
     hipStream_t stream = (hipStream_t)hip_stream;
-    if (d_stats) SR_HIP(hipMemsetAsync(d_stats, 0, 16 * sizeof(uint64_t), stream));
+    if (d_stats) SR_HIP(hipMemsetAsync(d_stats, 0, SR_STATS_COUNT * sizeof(uint64_t), stream));
     return render_common(s, f, (uint32_t*)d_pixels, stream, (unsigned long long*)d_stats);
 }
 
@@ -942,8 +942,8 @@ int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]
     SR_HIP(s->d_pixels.reserve((size_t)count * 4));
     unsigned long long* d_stats = nullptr;
     if (stats) {
-        SR_HIP(s->d_stats.reserve(16 * sizeof(uint64_t)));
-        SR_HIP(hipMemsetAsync(s->d_stats.p, 0, 16 * sizeof(uint64_t), nullptr));
+        SR_HIP(s->d_stats.reserve(SR_STATS_COUNT * sizeof(uint64_t)));
+        SR_HIP(hipMemsetAsync(s->d_stats.p, 0, SR_STATS_COUNT * sizeof(uint64_t), nullptr));
         d_stats = (unsigned long long*)s->d_stats.p;
     }
     if ((rc = render_common(s, f, (uint32_t*)s->d_pixels.p, nullptr, d_stats))) return rc;
@@ -959,7 +959,7 @@ int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]
         SR_HIP(hipMemcpy(pixels + off, (const int32_t*)s->d_pixels.p + off, n * 4, hipMemcpyDeviceToHost));
     }
     if (stats) {
-        SR_HIP(hipMemcpy(s->last_stats, s->d_stats.p, 16 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        SR_HIP(hipMemcpy(s->last_stats, s->d_stats.p, SR_STATS_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
         std::memcpy(stats, s->last_stats, 4 * sizeof(uint64_t));
     }
     return SR_OK;
@@ -1042,7 +1042,7 @@ int sr_get_triangles(const sr_scene* s, double* v9, uint32_t* argb, double box_m
     return SR_OK;
 }
 
-int sr_last_ray_stats(const sr_scene* s, uint64_t out[16]) {
+int sr_last_ray_stats(const sr_scene* s, uint64_t out[SR_STATS_COUNT]) {
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
     std::memcpy(out, s->last_stats, sizeof(s->last_stats));
     return SR_OK;

@@ -31,7 +31,7 @@ struct DevScene {
 };
 
 constexpr int kShaftRounds = 2;
-enum KernelId { K_RENDER = 0, K_TRACE = 1, K_PRIMARY = 2, K_SHADOW = 3, K_RESOLVE = 4, K_SHAFT = 5, K_FALLBACK = 6, K_SHAFT2 = 7, K_SHADOW2 = 8, K_POST = 9, K_ANTI_ALIAS = 10, K_COUNT = 11 };
+enum KernelId { K_RENDER = 0, K_TRACE = 1, K_PRIMARY = 2, K_SHADOW = 3, K_RESOLVE = 4, K_SHAFT = 5, K_FALLBACK = 6, K_SHAFT2 = 7, K_SHADOW2 = 8, K_POST = 9, K_ANTI_ALIAS = 10, K_BOUNCE = 11, K_COUNT = 12 };
 const char* kernel_name(int id);
 
 struct RenderLaunch {

@@ -149,6 +149,7 @@ const char* kernel_name(int id) {
         case K_RESOLVE: return "k_resolve";
         case K_SHAFT: return "k_shaft";
         case K_FALLBACK: return "k_shadow_fallback";
+        case K_BOUNCE: return "k_bounce";
         case K_SHAFT2: return "k_shaft_round2";
         case K_SHADOW2: return "k_shadow_round2";
         case K_POST: return "k_post_process";

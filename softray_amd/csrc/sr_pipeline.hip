@@ -1771,6 +1771,8 @@ __global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc,
         if (lane == 0) {
             stat_add(&stats[4], a); stat_add(&stats[5], b);
             stat_add(&stats[6], c2); stat_add(&stats[7], d2);
+            stat_add(&stats[16], a); stat_add(&stats[17], b);      // the exact fallback on its own: rays, FP64 records, nodes (per lane), leaves
+            stat_add(&stats[18], c2); stat_add(&stats[19], d2);
         }
     }
 }
@@ -1832,6 +1834,8 @@ __global__ __launch_bounds__(256) void k_shadow_wave(DevScene sc, FrameConst fc,
         if (lane == 0) {
             stat_add(&stats[4], a); stat_add(&stats[5], b);
             stat_add(&stats[6], c2); stat_add(&stats[7], d2);
+            stat_add(&stats[16], a); stat_add(&stats[17], b);
+            stat_add(&stats[18], c2); stat_add(&stats[19], d2);
         }
     }
 }
@@ -2023,7 +2027,10 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
     }
     if (STATS) {
         uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom), c2 = wave_sum(sec.nodes), d2 = wave_sum(sec.leaves);
-        if (lane == 0) { stat_add(&stats[4], a); stat_add(&stats[5], b); stat_add(&stats[6], c2); stat_add(&stats[7], d2); }
+        if (lane == 0) {
+            stat_add(&stats[4], a); stat_add(&stats[5], b); stat_add(&stats[6], c2); stat_add(&stats[7], d2);
+            stat_add(&stats[20], a); stat_add(&stats[21], b); stat_add(&stats[22], c2); stat_add(&stats[23], d2);   // mirror rays on their own
+        }
     }
 }
 
@@ -2368,7 +2375,7 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
             // counters: [0] / [1] ray counts of the two queues  [2] k_bounce's work head
             const long long band_n = (long long)row_count * L.fc.width * n2;
             hipEvent_t b0 = nullptr, b1 = nullptr;
-            if (L.get_events) L.get_events(L.user, K_FALLBACK, &b0, &b1);       // reported as "k_shadow_fallback": the secondary-ray family
+            if (L.get_events) L.get_events(L.user, K_BOUNCE, &b0, &b1);         // all levels' k_bounce launches + k_fold of this band
             if (b0 && (e = hipEventRecord(b0, L.stream)) != hipSuccess) return e;
             const size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
             const unsigned blocks = (unsigned)std::min<long long>((band_n + 255) / 256, (long long)L.persistent_blocks);

@@ -151,7 +151,7 @@ class GpuScene:
 
     def ray_stats(self):
         """primary {rays, tests, nodes, leaves} + secondary {rays, tests, nodes, leaves} of the last render(stats=True)."""
-        out = np.zeros(16, dtype=np.uint64)
+        out = np.zeros(24, dtype=np.uint64)                           # SR_STATS_COUNT
         _check(_lib.lib().sr_last_ray_stats(self._h, _p(out)))
         return out
 

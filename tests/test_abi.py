@@ -27,7 +27,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(L, n), "libsoftray_hip.so does not export %s" % n
     assert sorted(sa._lib.SYMBOLS) == names
-    assert L.sr_abi_version() == 3              # sr_debug_set / sr_bvh_stats, 16 ray statistics
+    assert L.sr_abi_version() == 4              # 24 ray statistics (SR_STATS_COUNT)
 
 
 def test_frame_layout_matches_oracle_frame():

@@ -301,3 +301,21 @@ def test_static_shadow_cache_outlives_the_frame():
     assert not np.array_equal(b_after_a, b_fresh)
     with pytest.raises(RuntimeError):                    # a frame split over ranks has no single fill order
         s.render(make_frame(32, shadows=True, static_shadows=True, strips=(4, 2, 0)))
+
+
+def test_render_window_draws_the_same_pixels():
+    """orc_render_window (the CPU baseline's centred crop in bench.py): the windowed pixels are orc_render's, the rest is untouched."""
+    o = orc.Scene()
+    o.set_triangles(*load_obj3ds())
+    assert o.build_tree() == 0
+    f = make_frame(48, 40, shadows=True)
+    full, _ = o.render(f, threads=4)
+    full = full.reshape(40, 48)
+    f.start_row, f.end_row = 9, 30
+    win = np.full(48 * 40, 7, dtype=np.int32)
+    got, _ = o.render(f, threads=3, out=win, cols=(5, 41))
+    got = got.reshape(40, 48)
+    assert np.array_equal(got[9:31, 5:41], full[9:31, 5:41])
+    mask = np.ones((40, 48), dtype=bool)
+    mask[9:31, 5:41] = False
+    assert (got[mask] == 7).all()
