@@ -201,6 +201,10 @@ int  sr_bvh_stats(const sr_scene*, int64_t out[4]);
 /* diagnostics: FNV-1a hashes of the host-built BVH's node array and of its leaf-ordered triangle indices (the host build must not
  * depend on the number of threads it ran on); SR_ERR_NOT_BUILT for a device-built tree */
 int  sr_bvh_digest(const sr_scene*, uint64_t out[2]);
+/* diagnostics: the four-children-per-node form of the host-built BVH that the wave-cooperative packet walks traverse (collapsed
+ * from the binary tree: same boxes, same leaves, same leaf order): out = depth, nodes, child slots in use, leaves, triangles
+ * in leaves; SR_ERR_NOT_BUILT for a device-built tree, SR_ERR_UNSUPPORTED if a link is broken */
+int  sr_wide_tree_stats(const sr_scene*, int64_t out[5]);
 
 /* Renderer.Render() for one Instance, raytrace path (Renderer.cs:701-778 -> RaytraceGeometry :1501 ->
  * RaytraceBlock :1690).  pixels = caller-owned int[W*H] ARGB, row-major pixels[row*W+col]
@@ -319,6 +323,8 @@ enum {
     SR_DBG_ROUND2_NODES   = 11,  /* node budget of a private shaft walk of the later rounds (0 = unlimited): walks that exceed it hand
                                     their undecided samples to the exact fallback */
     SR_DBG_BUILD_THREADS  = 12,  /* threads of the host BVH build (default: the host's cores, at most 16); read by the next sr_build    */
+    SR_DBG_BVH2_PACKETS   = 13,  /* > 0: the packet walks (k_primary, first shaft round) on the binary tree with a per-step vote instead of
+                                    the four-wide tree with per-frame ordered children: same pixels; cross-check and A/B measurement */
     SR_DBG_COUNT          = 16
 };
 int  sr_debug_set(sr_scene*, int32_t key, int64_t value);

@@ -30,11 +30,12 @@ SYMBOLS = [
     "sr_default_fov_depth", "sr_area_light_offsets", "sr_load_3ds", "sr_num_triangles", "sr_get_triangles",
     "sr_reset_kernel_times", "sr_kernel_times", "sr_last_ray_stats", "sr_make_random_triangles", "sr_debug_counters", "sr_last_error", "sr_abi_version",
     "sr_post_process", "sr_post_process_device", "sr_anti_alias", "sr_anti_alias_device", "sr_reset_shadow_cache",
-    "sr_debug_set", "sr_bvh_stats", "sr_bvh_digest", "sr_create_multi", "sr_device_count", "sr_shade_points",
+    "sr_debug_set", "sr_bvh_stats", "sr_bvh_digest", "sr_wide_tree_stats", "sr_create_multi", "sr_device_count", "sr_shade_points",
 ]
 # sr_debug_set keys (include/softray.h)
 (DBG_BAND_SAMPLES, DBG_ROUND_CAP0, DBG_ROUND_CAP1, DBG_SPLIT, DBG_FB_RAY_CAP, DBG_BVH_LEAF, DBG_KERNEL_SWITCH,
- DBG_KERNEL_TIMING, DBG_EXACT_SHADOW_TESTS, DBG_PER_LANE_SHAFT, DBG_PER_LANE_PRIMARY, DBG_ROUND2_NODES, DBG_BUILD_THREADS) = range(13)
+ DBG_KERNEL_TIMING, DBG_EXACT_SHADOW_TESTS, DBG_PER_LANE_SHAFT, DBG_PER_LANE_PRIMARY, DBG_ROUND2_NODES, DBG_BUILD_THREADS,
+ DBG_BVH2_PACKETS) = range(14)
 
 
 class Prim(C.Structure):
@@ -129,6 +130,7 @@ def lib():
     L.sr_debug_set.restype = i32; L.sr_debug_set.argtypes = [vp, i32, i64]
     L.sr_bvh_stats.restype = i32; L.sr_bvh_stats.argtypes = [vp, vp]
     L.sr_bvh_digest.restype = i32; L.sr_bvh_digest.argtypes = [vp, vp]
+    L.sr_wide_tree_stats.restype = i32; L.sr_wide_tree_stats.argtypes = [vp, vp]
     L.sr_create_multi.restype = i32; L.sr_create_multi.argtypes = [vp, i32, C.POINTER(vp)]
     L.sr_device_count.restype = i32; L.sr_device_count.argtypes = [vp]
     L.sr_shade_points.restype = i32; L.sr_shade_points.argtypes = [vp, vp, i64, vp, vp, vp, vp]

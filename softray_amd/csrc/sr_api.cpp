@@ -78,8 +78,19 @@ struct sr_scene {
     size_t      bvh_num_nodes = 0;
     // device state
     DBuf d_tris, d_extra, d_rnodes, d_rboxes, d_rleaf, d_bnodes, d_btris, d_bslab, d_v9, d_bcam;
-    double cam_origin[3] = {0, 0, 0};    // ray origin the camera-cone records in d_bcam were made for
+    double cam_origin[3] = {0, 0, 0};    // ray origin the camera-cone records in d_bcam (and the node order of d_b4cam) were made for
     bool   cam_valid = false;
+    // four-wide tree of the packet walks: build-order nodes + the two per-frame ordered copies (camera origin / point light)
+    DBuf d_b4, d_b4cam, d_b4light;
+    size_t b4_num = 0;
+    int    b4_depth = 0;
+    bool   b4cam_valid = false, b4light_valid = false;
+    double b4_light[3] = {0, 0, 0};      // light position the order of d_b4light was made for
+    // the per-origin / per-light records above are written on whatever stream the frame that needs them runs on: `pre_ready` is
+    // recorded after every rewrite and waited for by every frame (another stream may use them next), `pre_used` is recorded at the
+    // end of every frame that read them and waited for before the next rewrite
+    hipEvent_t pre_ready = nullptr, pre_used = nullptr;
+    bool pre_ready_set = false, pre_used_set = false;
     DBuf d_shadow_cache, d_static_claim, d_static_hits;
     bool shadow_cache_empty = true;      // the device cache must be zeroed before its next use
     DBuf d_pixels, d_aa, d_stats, d_io[9];
@@ -133,6 +144,19 @@ int use_device(sr_scene* s) {
     return SR_OK;
 }
 
+// the four-wide tree of the packet walks = the binary tree collapsed on the host (sr_host.cpp collapse_bvh4)
+int upload_wide_tree(sr_scene* s, const sr::BvhNode* nodes, size_t num_nodes) {
+    std::vector<sr::Bvh4Node> wide;
+    s->b4_depth = sr::collapse_bvh4(nodes, num_nodes, wide);
+    s->b4_num = wide.size();
+    s->b4cam_valid = s->b4light_valid = false;
+    if (s->pre_used_set) SR_HIP(hipEventSynchronize(s->pre_used));       // a frame in flight may still be walking the old tree's copies
+    SR_HIP(s->d_b4.upload(wide));
+    SR_HIP(s->d_b4cam.reserve(wide.size() * sizeof(sr::Bvh4Node)));
+    SR_HIP(s->d_b4light.reserve(wide.size() * sizeof(sr::Bvh4Node)));
+    return SR_OK;
+}
+
 int sync_geometry(sr_scene* s, uint32_t need_mode) {
     if (s->tris_dirty) { SR_HIP(s->d_tris.upload(s->tri_recs)); SR_HIP(s->d_v9.upload(s->v9)); s->tris_dirty = false; s->cam_valid = false; }
     if (s->extra_dirty) { SR_HIP(s->d_extra.upload(s->extra_recs)); s->extra_dirty = false; }
@@ -161,6 +185,8 @@ int sync_geometry(sr_scene* s, uint32_t need_mode) {
         s->bvh_num_nodes = s->bvh.nodes.size();
         s->bvh_dirty = false;
         s->cam_valid = false;
+        int rc = upload_wide_tree(s, s->bvh.nodes.data(), s->bvh.nodes.size());
+        if (rc) return rc;
     }
     return SR_OK;
 }
@@ -175,6 +201,9 @@ sr::DevScene dev_scene(const sr_scene* s) {
     d.bslab = (const sr::TriSlab*)s->d_bslab.p;
     d.bcam = s->cam_valid ? (const sr::CamCone*)s->d_bcam.p : nullptr;
     d.v9 = (const double*)s->d_v9.p;
+    d.b4cam = (s->b4cam_valid && s->cam_valid) ? (const sr::Bvh4Node*)s->d_b4cam.p : nullptr;
+    d.b4light = s->b4light_valid ? (const sr::Bvh4Node*)s->d_b4light.p : nullptr;
+    d.b4depth = s->b4_depth;
     d.bnode_bits = 1;
     while ((1ull << d.bnode_bits) < s->bvh_num_nodes + 1 && d.bnode_bits < 26) d.bnode_bits++;
     d.root = s->root;
@@ -359,16 +388,57 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         return SR_OK;
     }
     // ---- camera-cone records of the packet primary walk: one pre-pass per (tree, ray origin) ----
+    const bool wide = f->trace_mode == SR_MODE_BVH && s->b4_num > 0 && s->dbg[SR_DBG_BVH2_PACKETS] <= 0;
+    bool rewrote = false;
+    auto before_rewrite = [&]() -> hipError_t {                       // frames enqueued earlier (any stream) may still read the old records
+        if (rewrote || !s->pre_used_set) return hipSuccess;
+        return hipStreamWaitEvent(stream, s->pre_used, 0);
+    };
     if (f->trace_mode == SR_MODE_BVH && s->dbg[SR_DBG_PER_LANE_PRIMARY] <= 0 && !((f->flags & SR_F_FOCAL_BLUR) && f->sub_pixel_res > 1)) {
         const size_t nt = s->tri_recs.size();
-        if (!s->cam_valid || s->cam_origin[0] != fc.start_world[0] || s->cam_origin[1] != fc.start_world[1] || s->cam_origin[2] != fc.start_world[2]) {
+        const bool same_origin = s->cam_origin[0] == fc.start_world[0] && s->cam_origin[1] == fc.start_world[1] && s->cam_origin[2] == fc.start_world[2];
+        if (!s->cam_valid || !same_origin) {
             SR_HIP(s->d_bcam.reserve(nt * sizeof(sr::CamCone)));
+            SR_HIP(before_rewrite());
+            rewrote = true;
             s->cam_valid = false;
+            s->b4cam_valid = false;
             SR_HIP(sr::launch_cam_cones(dev_scene(s), (int)nt, fc.start_world, (sr::CamCone*)s->d_bcam.p, stream));
             for (int i = 0; i < 3; ++i) s->cam_origin[i] = fc.start_world[i];
             s->cam_valid = true;
         }
+        if (wide && !s->b4cam_valid) {                                // the four-wide nodes, children front to back for this origin
+            SR_HIP(before_rewrite());
+            rewrote = true;
+            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4cam.p, (int)s->b4_num, s->root, fc.start_world, false, stream));
+            s->b4cam_valid = true;
+        }
     }
+    if (wide && (fc.flags & SR_F_SHADOWS) && (fc.flags & SR_F_POINT_LIGHT)) {
+        const bool same_light = s->b4_light[0] == fc.light_pos_model[0] && s->b4_light[1] == fc.light_pos_model[1] && s->b4_light[2] == fc.light_pos_model[2];
+        if (!s->b4light_valid || !same_light) {                       // ... and nearest-to-the-surface first for this light
+            SR_HIP(before_rewrite());
+            rewrote = true;
+            s->b4light_valid = false;
+            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4light.p, (int)s->b4_num, s->root, fc.light_pos_model, true, stream));
+            for (int i = 0; i < 3; ++i) s->b4_light[i] = fc.light_pos_model[i];
+            s->b4light_valid = true;
+        }
+    }
+    if (rewrote) {
+        if (!s->pre_ready) SR_HIP(hipEventCreateWithFlags(&s->pre_ready, hipEventDisableTiming));
+        SR_HIP(hipEventRecord(s->pre_ready, stream));
+        s->pre_ready_set = true;
+    } else if (s->pre_ready_set) {
+        SR_HIP(hipStreamWaitEvent(stream, s->pre_ready, 0));          // written on another stream, perhaps: order this frame after it
+    }
+    struct MarkPreUsed {                                              // recorded when everything this frame enqueues is on the stream
+        sr_scene* s; hipStream_t st;
+        ~MarkPreUsed() {
+            if (!s->pre_used && hipEventCreateWithFlags(&s->pre_used, hipEventDisableTiming) != hipSuccess) return;
+            if (hipEventRecord(s->pre_used, st) == hipSuccess) s->pre_used_set = true;
+        }
+    } mark_pre_used{s, stream};
     // ---- default: the primary / shadow / resolve pipeline, in row bands ----
     const long long n2 = (long long)fc.sub_pixel_res * fc.sub_pixel_res;
     const bool shadows = (fc.flags & SR_F_SHADOWS) != 0;
@@ -492,6 +562,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.exact_shadow_tests = s->dbg[SR_DBG_EXACT_SHADOW_TESTS] > 0;
         P.per_lane_shaft = s->dbg[SR_DBG_PER_LANE_SHAFT] > 0 ? (int32_t)(s->dbg[SR_DBG_PER_LANE_SHAFT] & 3) : 0;
         P.per_lane_primary = s->dbg[SR_DBG_PER_LANE_PRIMARY] > 0;
+        P.bvh2_packets = s->dbg[SR_DBG_BVH2_PACKETS] > 0;
         P.round2_node_budget = s->dbg[SR_DBG_ROUND2_NODES] >= 0 ? (int32_t)std::min<int64_t>(s->dbg[SR_DBG_ROUND2_NODES], 1 << 30) : 0;
         P.stats = d_stats;
         P.stream = bs;
@@ -637,11 +708,13 @@ void sr_destroy(sr_scene* s) {
     }
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
-                        &s->d_v9, &s->d_bcam, &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_pixels, &s->d_aa, &s->d_stats};
+                        &s->d_v9, &s->d_bcam, &s->d_b4, &s->d_b4cam, &s->d_b4light, &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_pixels, &s->d_aa, &s->d_stats};
         for (DBuf* b : bufs) b->release();
         for (auto& sc : s->scratch) sc.release();
         for (auto& t : s->tables) { t.dev.release(); if (t.host) (void)hipHostFree(t.host); if (t.used) (void)hipEventDestroy(t.used); }
         if (s->fork) (void)hipEventDestroy(s->fork);
+        if (s->pre_ready) (void)hipEventDestroy(s->pre_ready);
+        if (s->pre_used) (void)hipEventDestroy(s->pre_used);
         if (s->multi_done) (void)hipEventDestroy(s->multi_done);
         for (DBuf& b : s->d_io) b.release();
         for (int k = 0; k < sr::K_COUNT; ++k)
@@ -772,6 +845,11 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         s->bvh_on_device = true;
         s->bvh_dirty = false;
         s->cam_valid = false;
+        {   // the four-wide tree is collapsed on the host from a copy of the device-built nodes
+            std::vector<sr::BvhNode> tmp((size_t)nn);
+            SR_HIP(hipMemcpy(tmp.data(), s->d_bnodes.p, (size_t)nn * sizeof(sr::BvhNode), hipMemcpyDeviceToHost));
+            if ((rc = upload_wide_tree(s, tmp.data(), tmp.size()))) return rc;
+        }
     } else if (modes & (1u << SR_MODE_BVH)) {
         sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(15, s->dbg[SR_DBG_BVH_LEAF]) : 7,
                       s->dbg[SR_DBG_BUILD_THREADS] > 0 ? (int)std::min<int64_t>(64, s->dbg[SR_DBG_BUILD_THREADS]) : 0);
@@ -802,6 +880,25 @@ int sr_bvh_stats(const sr_scene* s, int64_t out[4]) {
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
     if (!s->bvh.built) return fail(SR_ERR_NOT_BUILT, "BVH not built");
     out[0] = s->bvh.depth; out[1] = (int64_t)(s->bvh_on_device ? s->bvh_num_nodes : s->bvh.nodes.size()); out[2] = (int64_t)s->tri_recs.size(); out[3] = s->bvh_on_device ? 1 : 0;
+    return SR_OK;
+}
+
+int sr_wide_tree_stats(const sr_scene* s, int64_t out[5]) {
+    if (s && !s->parts.empty()) s = s->parts[0];
+    if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
+    if (!s->bvh.built || s->bvh_on_device) return fail(SR_ERR_NOT_BUILT, "no host-built BVH");
+    std::vector<sr::Bvh4Node> wide;
+    out[0] = sr::collapse_bvh4(s->bvh.nodes.data(), s->bvh.nodes.size(), wide);
+    out[1] = (int64_t)wide.size();
+    out[2] = out[3] = out[4] = 0;
+    std::vector<char> linked(wide.size(), 0);
+    for (const sr::Bvh4Node& n : wide)
+        for (const sr::Bvh4Child& c : n.ch) {
+            if (c.n < 0) continue;
+            out[2]++;                                                  // child slots in use
+            if (c.n > 0) { out[3]++; out[4] += c.n; }                  // leaves, triangles in leaves
+            else if (c.c <= 0 || (size_t)c.c >= wide.size() || linked[(size_t)c.c]++) return fail(SR_ERR_UNSUPPORTED, "wide tree: bad inner link");
+        }
     return SR_OK;
 }
 

@@ -26,6 +26,11 @@ struct DevScene {
     const double*  v9;          // model vertices [ntris][3][3], TriangleIndex order
     int32_t        bdepth;
     int32_t        bnode_bits;  // bits needed for a BVH node index (stack words pack node | bound)
+    // the same tree with four children per node (packet walks), children sorted per frame: front to back for the camera rays'
+    // origin / back to front for the point light (nullptr: not made -> the BVH2 packet walks run)
+    const Bvh4Node* b4cam;
+    const Bvh4Node* b4light;
+    int32_t        b4depth;
     RootBox        root;
     uint8_t*       shadow_cache; // static soft-shadow cache, 128^3 bytes, 0 = empty cell (SR_F_STATIC_SHADOWS frames)
 };
@@ -84,6 +89,7 @@ struct PipelineLaunch {
     int32_t     tile_queue_n2, tile_queue_rows; // (set by launch_pipeline) > 0: the hit queue of this band is tile-indexed
     int32_t     round2_node_budget; // later shaft rounds: a private walk gives up after this many nodes (0 = never)
     bool        per_lane_primary; // k_primary with private walks instead of the packet walk + camera-cone filter (cross-check)
+    bool        bvh2_packets;     // the packet walks on the two-wide tree with a per-step vote (round 2's kernels; cross-check)
     int32_t     per_lane_shaft;   // bit 0: k_shaft (private walks) for the first round instead of k_shaft_pkt, bit 1: for the later rounds instead of k_shaft_coop (cross-checks)
     bool        exact_shadow_tests; // k_shadow_test (every pair in FP64) instead of k_shadow_cls (fp32 classification first)
     unsigned long long* stats;  // device [8] or nullptr
@@ -92,6 +98,9 @@ struct PipelineLaunch {
     void*       user;
 };
 hipError_t launch_pipeline(const PipelineLaunch& L);
+// per-frame pre-pass: a copy of the four-wide nodes with every node's children sorted by the distance of their box centres from
+// `point` (model space), nearest first (camera origin) or farthest first (light: nearest to the surface points first)
+hipError_t launch_order_nodes(const Bvh4Node* in, Bvh4Node* out, int num_nodes, const RootBox& root, const double point[3], bool far_first, hipStream_t stream);
 // per-frame pre-pass: camera-cone records of every BVH triangle for the ray origin `origin` (model space)
 hipError_t launch_cam_cones(const DevScene& sc, int ntris, const double origin[3], CamCone* out, hipStream_t stream);
 size_t pipeline_hit_record_bytes();

@@ -492,6 +492,67 @@ void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int
     out.built = true;
 }
 
+int collapse_bvh4(const BvhNode* nodes, size_t num_nodes, std::vector<Bvh4Node>& out) {
+    out.clear();
+    if (num_nodes == 0) return 0;
+    out.reserve(num_nodes / 2 + 2);
+    auto child_of = [](const BvhNode& n, int side) {
+        Bvh4Child c;
+        for (int a = 0; a < 3; ++a) { c.lo[a] = side ? n.lo1[a] : n.lo0[a]; c.hi[a] = side ? n.hi1[a] : n.hi0[a]; }
+        c.c = side ? n.c1 : n.c0;
+        c.n = side ? n.n1 : n.n0;
+        return c;
+    };
+    auto area = [](const Bvh4Child& c) {
+        const double dx = (double)c.hi[0] - c.lo[0], dy = (double)c.hi[1] - c.lo[1], dz = (double)c.hi[2] - c.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    struct Item { int32_t src, dst, depth; };
+    std::vector<Item> stack;
+    out.push_back(Bvh4Node{});
+    stack.push_back({0, 0, 1});
+    int depth = 0;
+    while (!stack.empty()) {
+        const Item it = stack.back();
+        stack.pop_back();
+        depth = std::max(depth, it.depth);
+        Bvh4Child ch[4];
+        int k = 0;
+        for (int side = 0; side < 2; ++side) {
+            const Bvh4Child c = child_of(nodes[it.src], side);
+            if (c.n >= 0) ch[k++] = c;                                  // (empty children exist only in the root of a tiny scene)
+        }
+        while (k < 4) {
+            int best = -1;
+            double best_area = -1.0;
+            for (int i = 0; i < k; ++i)
+                if (ch[i].n == 0) { const double a = area(ch[i]); if (a > best_area) { best_area = a; best = i; } }
+            if (best < 0) break;
+            const BvhNode& m = nodes[ch[best].c];
+            const Bvh4Child l = child_of(m, 0), r = child_of(m, 1);
+            // the left child takes the parent's slot, the right one follows it: build (= spatial split) order is kept
+            for (int i = k; i > best + 1; --i) ch[i] = ch[i - 1];
+            ch[best] = l;
+            ch[best + 1] = r;
+            ++k;
+        }
+        for (int i = 0; i < k; ++i) {
+            if (ch[i].n == 0) {
+                const int32_t dst = (int32_t)out.size();
+                out.push_back(Bvh4Node{});
+                stack.push_back({ch[i].c, dst, it.depth + 1});
+                ch[i].c = dst;
+            }
+        }
+        for (int i = k; i < 4; ++i) {
+            for (int a = 0; a < 3; ++a) { ch[i].lo[a] = 1.0f; ch[i].hi[a] = -1.0f; }
+            ch[i].c = 0; ch[i].n = -1;
+        }
+        for (int i = 0; i < 4; ++i) out[it.dst].ch[i] = ch[i];
+    }
+    return depth;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Instance / Renderer helpers
 // ------------------------------------------------------------------------------------------------

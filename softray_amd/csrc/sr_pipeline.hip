@@ -76,7 +76,9 @@ static int xcd_tile_grid(int width, int row_count) {
 // SUB = false: one ray per pixel (rayTraceSubPixelRes == 1), compiled without the sub-pixel / focal-blur state
 // PKT (own BVH, all rays of the frame share one origin): the wave walks the tree once (bvh_packet_nearest, sr_trace.h) and
 // consults the frame's camera-cone records before the FP64 triangle test
-template <int MODE, bool EXTRA, bool STATS, bool SUB, bool PKT>
+// PKT = 2: the packet walk on the four-wide tree's camera-ordered copy (bvh4_packet_nearest), the default; PKT = 1: on the binary
+// tree with a per-step vote (cross-check)
+template <int MODE, bool EXTRA, bool STATS, bool SUB, int PKT>
 __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
                                                  int row_count, uint32_t* __restrict__ samples, HitRec* __restrict__ hits,
                                                  unsigned int* __restrict__ hit_count, uint32_t* __restrict__ bounce_levels,
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
         bool ok = false;
         if (PKT) {
             if (live) prim.rays++;
-            ok = root_intersect_pkt<EXTRA, true>(sc, sc.extra, wnode, live, ss, dw, h, prim);     // all 64 lanes take part
+            ok = root_intersect_pkt<EXTRA, true, PKT == 2>(sc, sc.extra, wnode, live, ss, dw, h, prim);     // all 64 lanes take part
         } else if (live) {
             prim.rays++;
             ok = root_intersect<MODE, false, EXTRA>(sc, sc.tris, sc.extra, st, ss, dw, h, prim);
@@ -849,6 +851,156 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc
             nu = first0 ? (w0 ? b0 : -1.0f) : (w1 ? b1 : -1.0f);
         } else if (any0) { ni = n.c0; nu = w0 ? b0 : -1.0f; }
         else if (any1) { ni = n.c1; nu = w1 ? b1 : -1.0f; }
+        else nu = -1.0f;                                               // leaf-only / dead end: pop at the top of the loop
+    }
+    if (valid) {
+        if (umbra) {
+            // fully shadowed: rayEscapeCount = 0 -> (byte)(0.0 * 255) = 0 -> ModulatePackedColor(color, 0) = opaque black
+            finish_hit(sc, fc, samples, rec.sample, rec.pad[0], (fc.flags & 32u) ? 0u : samples[rec.sample], 0.0);
+            cand_count[slot_i] = 0u;
+        } else if (count == 0 && !truncated && sc.nextra == 0) {
+            // nothing in the whole shaft and no extra geometry: every sample escapes (ShadowMethod.cs:113-119)
+            finish_hit(sc, fc, samples, rec.sample, rec.pad[0], (fc.flags & 32u) ? 0u : samples[rec.sample], (double)fc.shadow_samples / (double)fc.shadow_samples);
+            cand_count[slot_i] = 0u;
+        } else {
+            cand_count[slot_i] = (unsigned)count | (truncated ? kTruncated : 0u);
+            work_list[atomicAdd(work_count, 1u)] = slot_i;             // the compiler aggregates this per wavefront
+        }
+    }
+    if (STATS) {
+        const uint32_t d2 = wave_sum(valid ? 1u : 0u);
+        block_stat_add(&stats[6], &stats[7], &stats[10], &stats[11], nodes, leaves, slabs, d2);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_shaft_pkt4 -- the same packet walk on the FOUR-WIDE tree (Bvh4Node): a step fetches one 128-byte node (one pair of scalar
+// loads) and tests four children's boxes, so a tile's walk is about half as many dependent steps, scalar-cache round trips and
+// stack operations.  The nodes come from the frame's LIGHT-ordered copy (k_order_nodes): all shafts end in the same light, so
+// the children of a node are met in the same order by every shaft -- stored nearest-to-the-surface first.  No vote: leaf
+// children are filtered in slot order, the inner children that a live lane wants are pushed far to near (node word + one row
+// of per-lane u bounds each) and the nearest is entered.  Per-lane arithmetic (slab test, shaft_touches) is k_shaft_pkt's;
+// the candidate lists may differ in order and in which candidates a truncated list holds, which no later stage depends on.
+// LDS per wave: [levels] node words + [levels][64] 16-bit bounds, levels = 3 * b4depth + 2.
+// --------------------------------------------------------------------------------------------------
+template <bool STATS>
+__global__ __launch_bounds__(256, 7) void k_shaft_pkt4(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
+                                                    const unsigned int* __restrict__ hit_count, int cap, int levels, int tile_n2, int tile_rows,
+                                                    unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
+                                                    uint32_t* __restrict__ samples, unsigned int* __restrict__ work_count,
+                                                    unsigned int* __restrict__ work_list, unsigned long long* stats) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int32_t* wnode = reinterpret_cast<int32_t*>(lds_pipe) + (size_t)wave * ((size_t)levels * 33);   // [levels] stacked node
+    // [levels][64] per-lane u bound, 16 bits: 0 = the lane's shaft misses the subtree, else 1 + the bound in 1/65534 rounded UP
+    uint16_t* wbound = reinterpret_cast<uint16_t*>(wnode + levels) + lane;
+    const unsigned int total = *hit_count;
+    unsigned int slot_i = blockIdx.x * 256u + (unsigned)tid;
+    if (tile_n2 > 0) {
+        // tile-indexed queue (see k_primary): block b * n2 + sub-sample of this grid <-> block b of k_primary, same XCD
+        int tile_x, tile_y;
+        const int pb = (int)blockIdx.x / tile_n2, si = (int)blockIdx.x - pb * tile_n2;
+        if (!xcd_tile(pb, fc.width, tile_rows, tile_x, tile_y)) return;
+        const int tiles_x = (fc.width + 15) >> 4;
+        slot_i = ((unsigned)(tile_y * tiles_x + tile_x) * (unsigned)tile_n2 + (unsigned)si) * 256u + (unsigned)tid;
+    }
+    HitRec rec;
+    rec.sample = kInvalidHit;
+    if (slot_i < total) rec = hits[slot_i];
+    const bool valid = rec.sample != kInvalidHit;
+    uint32_t nodes = 0, leaves = 0, slabs = 0;                    // wave-level (uniform)
+    const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
+    const D3 E = valid ? mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001 : lpos * 0.5;   // ShadowMethod.cs:151
+    const float R = (float)fc.light_radius * 1.00001f + 1e-30f;
+    float ext = 0.0f;
+    for (int a = 0; a < 3; ++a) ext = fmaxf(ext, (float)(sc.root.max[a] - sc.root.min[a]));
+    const float pad = ext * 3.0517578125e-5f;                          // 2^-15 * extent (boxes carry 2^-16 already)
+    const float ex = (float)(E.x - sc.root.centre[0]), ey = (float)(E.y - sc.root.centre[1]), ez = (float)(E.z - sc.root.centre[2]);
+    const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
+    const float ix = slab_inv(dx), iy = slab_inv(dy), iz = slab_inv(dz);
+    const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
+    const f2 OI01 = {-ex * ix, -ey * iy}, OI20 = {-ez * iz, -ex * ix}, OI12 = {-ey * iy, -ez * iz};
+    const f2 RI01 = {-ix, -iy}, RI20 = {-iz, ix}, RI12 = {iy, iz};
+    const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
+    const ShaftRay sr = make_shaft_ray(sc, fc, E, lpos);
+    int32_t* out = cand + (size_t)slot_i * cap;
+    int count = 0;
+    bool truncated = false, umbra = false;
+    bool done = !valid;
+    int sp = 0;                      // wave-uniform
+    int32_t ni = 0;                  // wave-uniform: current inner node
+    float nu = valid ? 1.0f : -1.0f; // this lane's u bound inside the current subtree; < 0: the lane's shaft misses it
+    auto enc = [](float fb) { return fb < 0.0f ? (uint16_t)0 : (uint16_t)min(65535, (int)(fminf(fb, 1.0f) * 65534.0f) + 2); };
+    for (;;) {
+        if (__ballot(!done && nu >= 0.0f) == 0ull) {
+            if (__ballot(!done) == 0ull) break;                        // every lane has its verdict: nothing on the stack matters
+            // nobody wants the current subtree: pop until a live lane wants one
+            bool found = false;
+            while (sp > 0) {
+                --sp;
+                const uint32_t qb = wbound[sp * 64];
+                const float bu = qb ? (float)(qb - 1u) * (1.0f / 65534.0f) * 1.000001f : -1.0f;
+                if (__ballot(!done && bu >= 0.0f) != 0ull) { ni = __builtin_amdgcn_readfirstlane(wnode[sp]); nu = bu; found = true; break; }
+            }
+            if (!found) break;
+        }
+        const Bvh4Node n = sc.b4light[ni];                             // wave-uniform address: scalar loads
+        nodes++;
+        const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
+        const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
+        float a0, b0, a1, b1, a2, b2, a3, b3;                          // child u-intervals [a, b] of this lane's shaft
+        child_slabs(n.ch[0], I01, I20, I12, B0, B1, B2, a0, b0);
+        child_slabs(n.ch[1], I01, I20, I12, B0, B1, B2, a1, b1);
+        child_slabs(n.ch[2], I01, I20, I12, B0, B1, B2, a2, b2);
+        child_slabs(n.ch[3], I01, I20, I12, B0, B1, B2, a3, b3);
+        b0 = fminf(b0, nu); b1 = fminf(b1, nu); b2 = fminf(b2, nu); b3 = fminf(b3, nu);
+        const bool h0 = !done && n.ch[0].n >= 0 && fmaxf(a0, umin) <= b0, h1 = !done && n.ch[1].n >= 0 && fmaxf(a1, umin) <= b1;
+        const bool h2 = !done && n.ch[2].n >= 0 && fmaxf(a2, umin) <= b2, h3 = !done && n.ch[3].n >= 0 && fmaxf(a3, umin) <= b3;
+        // ---- leaf children in slot order: every interested lane filters the (broadcast) triangles with its own shaft ----
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const int cn = pick4(k, n.ch[0].n, n.ch[1].n, n.ch[2].n, n.ch[3].n);
+            if (cn <= 0) continue;
+            const bool hc = pick4(k, h0, h1, h2, h3);
+            if (__ballot(hc && !done) == 0ull) continue;
+            const int cc = pick4(k, n.ch[0].c, n.ch[1].c, n.ch[2].c, n.ch[3].c);
+            leaves++;
+            slabs += (uint32_t)cn;
+            for (int q = 0; q < cn; ++q) {
+                const TriSlab s = sc.bslab[cc + q];                   // scalar load
+                const bool live_q = hc && !done;
+                const int touch = shaft_touches(s, sr, live_q);
+                const bool take = live_q && touch != 0, room = count < cap;
+                if (take && room) out[count] = cc + q;
+                count += (take && room) ? 1 : 0;
+                truncated = truncated || (take && !room);
+                umbra = umbra || (live_q && touch == 2);
+                done = done || truncated || umbra;
+            }
+        }
+        // ---- inner children, far to near: the nearest one a live lane wants is entered, the others wait on the stack ----
+        int32_t next = -1;
+        float next_u = -1.0f;
+        {
+            const bool w3 = h3 && !done && n.ch[3].n == 0;
+            if (__ballot(w3) != 0ull) { next = n.ch[3].c; next_u = w3 ? b3 : -1.0f; }
+            const bool w2 = h2 && !done && n.ch[2].n == 0;
+            if (__ballot(w2) != 0ull) {
+                if (next >= 0) { wnode[sp] = next; wbound[sp * 64] = enc(next_u); sp++; }
+                next = n.ch[2].c; next_u = w2 ? b2 : -1.0f;
+            }
+            const bool w1 = h1 && !done && n.ch[1].n == 0;
+            if (__ballot(w1) != 0ull) {
+                if (next >= 0) { wnode[sp] = next; wbound[sp * 64] = enc(next_u); sp++; }
+                next = n.ch[1].c; next_u = w1 ? b1 : -1.0f;
+            }
+            const bool w0 = h0 && !done && n.ch[0].n == 0;
+            if (__ballot(w0) != 0ull) {
+                if (next >= 0) { wnode[sp] = next; wbound[sp * 64] = enc(next_u); sp++; }
+                next = n.ch[0].c; next_u = w0 ? b0 : -1.0f;
+            }
+        }
+        if (next >= 0) { ni = next; nu = next_u; }
         else nu = -1.0f;                                               // leaf-only / dead end: pop at the top of the loop
     }
     if (valid) {
@@ -2159,6 +2311,46 @@ __global__ __launch_bounds__(256) void k_cam_cones(const Rec128* __restrict__ bt
     out[i] = c;
 }
 
+// --------------------------------------------------------------------------------------------------
+// k_order_nodes: per-frame pre-pass of the four-wide packet walks -- a copy of the node array in which every node's children are
+// sorted by the squared distance of their box centres from one point (fp32, root-centre-relative like the boxes): nearest first
+// for the camera rays' origin, farthest first for the point light (= nearest to the surface points first).  Empty slots go last.
+// Links are untouched (a child keeps its node index), only the slots move; the sort is stable, so equal keys keep build order.
+// 128 B read + 128 B written per node: 17 MB at 1 M triangles; re-run only when the point or the tree changed.
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_order_nodes(const Bvh4Node* __restrict__ in, Bvh4Node* __restrict__ out, int n, float px, float py, float pz, int far_first) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    Bvh4Node nd = in[i];
+    float key[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const Bvh4Child& c = nd.ch[k];
+        const float cx = 0.5f * (c.lo[0] + c.hi[0]) - px, cy = 0.5f * (c.lo[1] + c.hi[1]) - py, cz = 0.5f * (c.lo[2] + c.hi[2]) - pz;
+        const float d2 = cx * cx + cy * cy + cz * cz;
+        key[k] = c.n < 0 ? FLT_MAX : (far_first ? -d2 : d2);
+    }
+    // stable insertion sort of four (fully unrolled: registers only)
+#pragma unroll
+    for (int a = 1; a < 4; ++a) {
+#pragma unroll
+        for (int b = a; b > 0; --b) {
+            if (key[b] < key[b - 1]) {
+                const float tk = key[b]; key[b] = key[b - 1]; key[b - 1] = tk;
+                const Bvh4Child tc = nd.ch[b]; nd.ch[b] = nd.ch[b - 1]; nd.ch[b - 1] = tc;
+            }
+        }
+    }
+    out[i] = nd;
+}
+
+hipError_t launch_order_nodes(const Bvh4Node* in, Bvh4Node* out, int num_nodes, const RootBox& root, const double point[3], bool far_first, hipStream_t stream) {
+    if (num_nodes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_order_nodes, dim3((unsigned)((num_nodes + 255) / 256)), dim3(256), 0, stream, in, out, num_nodes,
+                       (float)(point[0] - root.centre[0]), (float)(point[1] - root.centre[1]), (float)(point[2] - root.centre[2]), far_first ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_cam_cones(const DevScene& sc, int ntris, const double origin[3], CamCone* out, hipStream_t stream) {
     if (ntris <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_cam_cones, dim3((unsigned)((ntris + 255) / 256)), dim3(256), 0, stream, sc.btris, sc.bslab, sc.v9, ntris,
@@ -2175,11 +2367,11 @@ static int pipe_stack_levels(const DevScene& sc, int mode) {
     return 1;
 }
 
-template <int MODE, bool EXTRA, bool SUB, bool PKT>
+template <int MODE, bool EXTRA, bool SUB, int PKT>
 static hipError_t launch_primary_p(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples, int pad_tiles) {
     // 1-D grid over the padded super-tile grid (see the tile order in k_primary)
     dim3 grid((unsigned)xcd_tile_grid(L.fc.width, row_count));
-    const int levels = pipe_stack_levels(L.sc, MODE);
+    const int levels = PKT == 2 ? 3 * L.sc.b4depth + 2 : pipe_stack_levels(L.sc, MODE);
     size_t lds = PKT ? (size_t)levels * 4 * 4 : (size_t)levels * 256 * 4;
     if (L.stats)
         hipLaunchKernelGGL((k_primary<MODE, EXTRA, true, SUB, PKT>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
@@ -2195,9 +2387,12 @@ static hipError_t launch_primary_s(const PipelineLaunch& L, int row_begin, int r
     if constexpr (MODE == MODE_BVH) {
         // packet walk + camera-cone filter: the rays of the frame must share their origin (focal blur moves it per sub-sample)
         const bool common_origin = !(SUB && (L.fc.flags & 4u));
-        if (L.sc.bcam && common_origin && !L.per_lane_primary) return launch_primary_p<MODE, EXTRA, SUB, true>(L, row_begin, row_count, samples, pad_tiles);
+        if (L.sc.bcam && common_origin && !L.per_lane_primary) {
+            if (L.sc.b4cam && !L.bvh2_packets) return launch_primary_p<MODE, EXTRA, SUB, 2>(L, row_begin, row_count, samples, pad_tiles);
+            return launch_primary_p<MODE, EXTRA, SUB, 1>(L, row_begin, row_count, samples, pad_tiles);
+        }
     }
-    return launch_primary_p<MODE, EXTRA, SUB, false>(L, row_begin, row_count, samples, pad_tiles);
+    return launch_primary_p<MODE, EXTRA, SUB, 0>(L, row_begin, row_count, samples, pad_tiles);
 }
 
 template <int MODE, bool EXTRA>
@@ -2258,8 +2453,16 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         {
             const int levels = pipe_stack_levels(L.sc, MODE_BVH);
             unsigned blocks = (unsigned)((max_items + 255) / 256);
-            if (first && !(L.per_lane_shaft & 1)) {
-                // round 1: one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
+            if (first && !(L.per_lane_shaft & 1) && L.sc.b4light && !L.bvh2_packets) {
+                // round 1 (default): one packet walk on the four-wide, light-ordered tree per 64 consecutive queue entries
+                const int lv4 = 3 * L.sc.b4depth + 2;
+                size_t lds = ((size_t)lv4 * 4 + (size_t)lv4 * 64 * 2) * 4;
+                const int tn2 = L.tile_queue_n2, trows = L.tile_queue_rows;
+                if (tn2 > 0) blocks = (unsigned)(xcd_tile_grid(L.fc.width, trows) * tn2);      // the grid of k_primary (x sub-samples)
+                if (L.stats) hipLaunchKernelGGL((k_shaft_pkt4<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
+                else hipLaunchKernelGGL((k_shaft_pkt4<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
+            } else if (first && !(L.per_lane_shaft & 1)) {
+                // round 1 on the binary tree (cross-check): one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
                 size_t lds = ((size_t)levels * 4 + (size_t)levels * 64 * 2) * 4;
                 const int tn2 = L.tile_queue_n2, trows = L.tile_queue_rows;
                 if (tn2 > 0) blocks = (unsigned)(xcd_tile_grid(L.fc.width, trows) * tn2);      // the grid of k_primary (x sub-samples)

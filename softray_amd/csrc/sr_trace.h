@@ -486,8 +486,113 @@ __device__ bool bvh_packet_nearest(const DevScene& sc, int32_t* wnode, bool live
     return true;
 }
 
+// --------------------------------------------------------------------------------------------------
+// The packet walk on the FOUR-WIDE tree (Bvh4Node, sr_types.h): one pair of scalar loads brings four children's boxes, so a
+// tile's walk is about half as many dependent steps (and half the scalar bookkeeping) as on the binary tree.  The nodes come
+// from the frame's camera-ordered copy (k_order_nodes): children are stored front to back for the rays' common origin, so
+// there is no vote -- leaves are tested in slot order, the inner children that some lane still wants are pushed far to
+// near and the nearest one is entered.  Per-lane arithmetic (slab tests, cone filter, FP64 triangle test) and therefore the
+// result are those of bvh_packet_nearest / bvh_intersect<false>: the nearest hit with the lowest-index tie-break does not
+// depend on the visiting order.  wnode: 3 * b4depth + 2 words.
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void child_slabs(const Bvh4Child& ch, f2 I01, f2 I20, f2 I12, f2 B0, f2 B1, f2 B2, float& a, float& b) {
+    const f2 T0 = pk_fma((f2){ch.lo[0], ch.lo[1]}, I01, B0), T1 = pk_fma((f2){ch.lo[2], ch.hi[0]}, I20, B1), T2 = pk_fma((f2){ch.hi[1], ch.hi[2]}, I12, B2);
+    a = fmaxf(fmaxf(fminf(T0.x, T1.y), fminf(T0.y, T2.x)), fminf(T1.x, T2.y));
+    b = fminf(fminf(fmaxf(T0.x, T1.y), fmaxf(T0.y, T2.x)), fmaxf(T1.x, T2.y));
+}
+// value k of four with a wave-uniform k (scalar selects / v_cndmask with scalar conditions: no indexed registers, no scratch)
+template <class T> __device__ __forceinline__ T pick4(int k, T a, T b, T c, T d) { return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d)); }
+
+template <bool FILTER>
+__device__ bool bvh4_packet_nearest(const DevScene& sc, int32_t* wnode, bool live, D3 s, D3 d, Hit& out, Ctr& c) {
+    D3 end = s + d * 10000.0;
+    D3 original = s;
+    bool act = live;
+    if (act) act = clip_segment<false>(sc.root, s, end);
+    const double offset = act ? length(original - s) / length(d) : 0.0;
+    const float ox = (float)(s.x - sc.root.centre[0]), oy = (float)(s.y - sc.root.centre[1]), oz = (float)(s.z - sc.root.centre[2]);
+    const float dfx = (float)d.x, dfy = (float)d.y, dfz = (float)d.z;
+    const float ix = slab_inv(dfx), iy = slab_inv(dfy), iz = slab_inv(dfz);
+    const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
+    const f2 B0 = {-ox * ix, -oy * iy}, B1 = {-oz * iz, -ox * ix}, B2 = {-oy * iy, -oz * iz};
+    const f2 dxx = splat(dfx), dyy = splat(dfy), dzz = splat(dfz);
+    const float dl = sqrtf(dfx * dfx + dfy * dfy + dfz * dfz) * 1.000001f;
+    const float kInfl = 1.0f + 9.5367431640625e-7f;          // 1 + 2^-20
+    float tlim = FLT_MAX;
+    double best = DBL_MAX;
+    int32_t bestIdx = 0x7fffffff, bestK = -1;
+    int sp = 0;                      // wave-uniform
+    int32_t ni = 0;                  // wave-uniform
+    const bool counter_lane = act && (__ffsll((long long)__ballot(act)) - 1) == (int)(threadIdx.x & 63u);
+    if (__ballot(act) != 0ull) {
+        for (;;) {
+            const Bvh4Node n = sc.b4cam[ni];                           // wave-uniform address: scalar loads
+            if (counter_lane) c.nodes++;                               // (per WAVE: 128-byte nodes fetched)
+            float t0, x0, t1, x1, t2, x2, t3, x3;
+            child_slabs(n.ch[0], I01, I20, I12, B0, B1, B2, t0, x0);
+            child_slabs(n.ch[1], I01, I20, I12, B0, B1, B2, t1, x1);
+            child_slabs(n.ch[2], I01, I20, I12, B0, B1, B2, t2, x2);
+            child_slabs(n.ch[3], I01, I20, I12, B0, B1, B2, t3, x3);
+            const bool h0 = act && n.ch[0].n >= 0 && t0 <= x0 && x0 >= 0.0f, h1 = act && n.ch[1].n >= 0 && t1 <= x1 && x1 >= 0.0f;
+            const bool h2 = act && n.ch[2].n >= 0 && t2 <= x2 && x2 >= 0.0f, h3 = act && n.ch[3].n >= 0 && t3 <= x3 && x3 >= 0.0f;
+            // ---- leaf children in slot order (front to back for this origin) ----
+#pragma unroll 1
+            for (int k = 0; k < 4; ++k) {
+                const int cn = pick4(k, n.ch[0].n, n.ch[1].n, n.ch[2].n, n.ch[3].n);
+                if (cn <= 0) continue;
+                const int cc = pick4(k, n.ch[0].c, n.ch[1].c, n.ch[2].c, n.ch[3].c);
+                const bool hc = pick4(k, h0, h1, h2, h3) && pick4(k, t0, t1, t2, t3) <= tlim;      // tlim may have shrunk in an earlier leaf
+                if (__ballot(hc) == 0ull) continue;
+                const bool hc_first = hc && (__ffsll((long long)__ballot(hc)) - 1) == (int)(threadIdx.x & 63u);
+                for (int q = cc; q < cc + cn; ++q) {
+                    bool cand = hc;
+                    if (FILTER) {
+                        const CamCone cm = sc.bcam[q];                               // scalar load
+                        cand = hc && !cone_rejects(cm, dxx, dyy, dzz, dl);
+                    }
+                    if (hc_first) c.geom++;
+                    if (__ballot(cand) != 0ull) {
+                        const Rec128* r = &sc.btris[q];                               // wave-uniform address
+                        if (cand && (__ffsll((long long)__ballot(cand)) - 1) == (int)(threadIdx.x & 63u)) c.leaves++;
+                        if (cand) {
+                            double tt; D3 pos;
+                            if (tri_hit(r->p, s, d, tt, pos) && inside(sc.root.lo, sc.root.hi, pos)) {
+                                const int32_t idx = r->aux;
+                                if (tt < best || (tt == best && idx < bestIdx)) {
+                                    best = tt; bestIdx = idx; bestK = q;
+                                    tlim = (float)best * kInfl + 1e-30f;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            // ---- inner children: far to near; the nearest one some lane wants is entered, the others wait on the stack ----
+            int32_t next = -1;
+            if (n.ch[3].n == 0 && __ballot(h3 && t3 <= tlim) != 0ull) next = n.ch[3].c;
+            if (n.ch[2].n == 0 && __ballot(h2 && t2 <= tlim) != 0ull) { if (next >= 0) wnode[sp++] = next; next = n.ch[2].c; }
+            if (n.ch[1].n == 0 && __ballot(h1 && t1 <= tlim) != 0ull) { if (next >= 0) wnode[sp++] = next; next = n.ch[1].c; }
+            if (n.ch[0].n == 0 && __ballot(h0 && t0 <= tlim) != 0ull) { if (next >= 0) wnode[sp++] = next; next = n.ch[0].c; }
+            if (next >= 0) ni = next;
+            else {
+                if (sp == 0) break;
+                ni = __builtin_amdgcn_readfirstlane(wnode[--sp]);
+            }
+        }
+    }
+    if (bestK < 0) return false;
+    const Rec128* r = &sc.btris[bestK];
+    out.t = best + offset;
+    out.pos = s + d * best;          // the expression plane_hit evaluated for the winning triangle (pos = start + dir * rayFrac)
+    out.nrm = mk(r->p[0], r->p[1], r->p[2]);
+    out.color = r->color;
+    out.tri = r->aux;
+    return true;
+}
+
 // root of the chain for a wavefront of rays with a common origin: extra geometry per lane, then the packet walk
-template <bool EXTRA, bool FILTER>
+// (WIDE: on the four-wide tree's camera-ordered copy)
+template <bool EXTRA, bool FILTER, bool WIDE = false>
 __device__ bool root_intersect_pkt(const DevScene& sc, const Rec128* extra, int32_t* wnode, bool live, D3 s, D3 d, Hit& out, Ctr& c) {
     bool any = false;
     double best = DBL_MAX;
@@ -508,7 +613,8 @@ __device__ bool root_intersect_pkt(const DevScene& sc, const Rec128* extra, int3
         }
     }
     Hit mh;
-    if (bvh_packet_nearest<FILTER>(sc, wnode, live, s, d, mh, c) && mh.t < best) { out = mh; any = true; }
+    const bool model = WIDE ? bvh4_packet_nearest<FILTER>(sc, wnode, live, s, d, mh, c) : bvh_packet_nearest<FILTER>(sc, wnode, live, s, d, mh, c);
+    if (model && mh.t < best) { out = mh; any = true; }
     return any;
 }
 

@@ -53,6 +53,22 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
+// The same tree collapsed to four children per node for the wave-cooperative PACKET walks (k_primary, k_shaft_pkt): 128 B = two
+// lines, fetched by ONE pair of scalar loads per step.  A child record is a BvhNode half: fp32 box (same frame, same padding:
+// the collapse copies the BVH2 boxes bit for bit) + link + count.  n > 0: leaf of n triangles, c = first record in leaf order;
+// n == 0: inner node index c (into the Bvh4Node array); n < 0: empty slot.  The children of the stored tree are in build order;
+// the walks read per-frame COPIES whose children are sorted front to back for the frame's ray origin / back to front for its
+// light (k_order_nodes): rays with a common origin (or a common end) meet the subtrees of a node in the same order whatever
+// their direction, so a packet walk needs no per-step vote -- slot 0 first, the others pushed far to near.
+struct alignas(16) Bvh4Child {
+    float   lo[3], hi[3];
+    int32_t c, n;
+};
+struct alignas(128) Bvh4Node {
+    Bvh4Child ch[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
+
 // fp32 conservative description of one triangle for the shadow-shaft walk (64 B = one line), in coordinates
 // relative to the root-box centre: the plane (unit normal n, offset d) and the three edge planes (unit in-plane
 // normals m_k pointing inward, offsets c_k).  A point within distance rho of the triangle satisfies

@@ -97,6 +97,12 @@ class GpuScene:
         _check(_lib.lib().sr_bvh_stats(self._h, _p(out)))
         return tuple(int(x) for x in out)
 
+    def wide_tree_stats(self):
+        """(depth, nodes, child slots in use, leaves, triangles in leaves) of the four-wide form of the host-built BVH."""
+        out = np.zeros(5, dtype=np.int64)
+        _check(_lib.lib().sr_wide_tree_stats(self._h, _p(out)))
+        return tuple(int(x) for x in out)
+
     def bvh_digest(self):
         """(hash of the node array, hash of the leaf-ordered triangle indices) of the host-built BVH."""
         out = np.zeros(2, dtype=np.uint64)

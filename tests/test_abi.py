@@ -83,6 +83,25 @@ def test_host_bvh_build_does_not_depend_on_the_thread_count():
     assert tris == 200000 and on_device == 0 and 200000 / 7 <= nodes < 200000 and 15 <= depth <= 60
 
 
+def test_wide_tree_is_the_binary_tree_collapsed():
+    """The four-wide tree of the packet walks (sr_host.cpp collapse_bvh4) holds exactly the binary tree's leaves: every triangle in
+    one leaf, as many leaves as the binary tree has (inner nodes + 1), every node but the root linked once, between a third and all of the depth."""
+    for n, seed in ((1, 1), (5, 2), (9, 3), (300, 4), (50000, 5)):
+        v9, argb = sa.make_random_triangles(n, seed, space=0.9, extent=0.1, origin=-0.5, opaque=True)
+        s = sa.GpuScene(device=-1)
+        s.set_triangles(v9, argb, np.array([-0.5] * 3), np.array([0.5] * 3))
+        s.build((sa.MODE_BVH,))
+        depth2, nodes2, tris, _ = s.bvh_stats()
+        depth4, nodes4, slots, leaves, leaf_tris = s.wide_tree_stats()
+        assert leaf_tris == tris == n
+        leaves2 = nodes2 + 1 if n > 7 else 1            # (a scene that fits one leaf: a root record with one leaf child)
+        assert leaves == leaves2, (n, leaves, leaves2)
+        assert slots == leaves + nodes4 - 1             # every node but the root sits in exactly one slot
+        assert nodes4 <= nodes2 and depth4 <= depth2 and 3 * depth4 >= depth2 - 2
+        if n >= 300:
+            assert slots / nodes4 > 3.0                  # the greedy collapse fills the nodes
+
+
 def test_no_cpu_fallback():
     s = sa.GpuScene(device=-1)                       # host-only scene
     v9, argb, bmin, bmax = load_obj3ds()

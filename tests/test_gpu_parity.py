@@ -1,5 +1,6 @@
 """GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the
 same inputs and against the reference's golden BMPs.  Bar: bit-exact ARGB / bit-exact doubles."""
+import math
 import os
 
 import numpy as np
@@ -427,7 +428,27 @@ def test_packet_shaft_walk_against_private_walks():
                 g.debug_set(sa._lib.DBG_PER_LANE_SHAFT, per_lane)
                 got, _ = g.render(as_sr(f, sa.MODE_BVH))
                 assert np.array_equal(got, want), (kw, caps, per_lane)
+            # the packet walks on the binary tree with a per-step vote (round 2's kernels) instead of the four-wide, per-frame
+            # ordered tree: a third schedule of the same lists
+            g.debug_set(sa._lib.DBG_PER_LANE_SHAFT, 0)
+            g.debug_set(sa._lib.DBG_BVH2_PACKETS, 1)
+            got, _ = g.render(as_sr(f, sa.MODE_BVH))
+            g.debug_set(sa._lib.DBG_BVH2_PACKETS, -1)
+            assert np.array_equal(got, want), (kw, caps, "bvh2 packets")
     g.debug_set(sa._lib.DBG_PER_LANE_SHAFT, -1)
+    # a light INSIDE the scene's box and one very close to the surface: the light-ordered copy of the nodes has no preferred side
+    for lp in ((0.05, 0.1, -0.02), (0.3, 0.45, 0.2)):
+        f = make_frame(96, 80, depth=1.5, shadows=True)
+        t, it = sa.instance_matrices([0.0, 0.0, 1.5], 135.0 / 180.0 * math.pi, -22.0 / 180.0 * math.pi, 0.0)
+        # light_pos_view such that inverseTransform(3x4) * pos lands on `lp` (model space): pos = transform(3x4) * lp
+        for r in range(3):
+            f.light_pos_view[r] = t[4 * r] * lp[0] + t[4 * r + 1] * lp[1] + t[4 * r + 2] * lp[2] + t[4 * r + 3]
+        want, _ = o.render(f, threads=NCPU)
+        for b2 in (-1, 1):
+            g.debug_set(sa._lib.DBG_BVH2_PACKETS, b2)
+            got, _ = g.render(as_sr(f, sa.MODE_BVH))
+            assert np.array_equal(got, want), (lp, b2)
+    g.debug_set(sa._lib.DBG_BVH2_PACKETS, -1)
 
 
 def test_packet_primary_walk_against_private_walks():
@@ -456,6 +477,13 @@ def test_packet_primary_walk_against_private_walks():
             assert np.array_equal(st, st2)
             stats.append(st)
         assert stats[0][0] == stats[1][0]                  # rays fired
+        # the packet walk on the binary tree (per-step vote) instead of the four-wide, camera-ordered tree
+        g.debug_set(sa._lib.DBG_PER_LANE_PRIMARY, 0)
+        g.debug_set(sa._lib.DBG_BVH2_PACKETS, 1)
+        got, st = g.render(as_sr(f, sa.MODE_BVH))
+        g.debug_set(sa._lib.DBG_BVH2_PACKETS, -1)
+        assert np.array_equal(got, want), (kw, "bvh2 packets")
+        assert st[0] == stats[0][0]
     g.debug_set(sa._lib.DBG_PER_LANE_PRIMARY, -1)
     prims = c1_spheres(7)
     prims.append((1, 0xff808080, [0, -0.45, 0, 0, 1, 0]))
