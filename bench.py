@@ -464,6 +464,23 @@ def main():
                         "each step alone, max over ranks, best of %d; in the timed region they overlap the next frame's rendering" % (reps, reps),
             }
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        # ---- the drop-in call: what the reference's synchronous Renderer.Render() maps to (Renderer.cs:701-778, caller-owned int[] :593):
+        #      a BLOCKING sr_render into a plain, pageable, already-touched numpy array; wall time per call ----
+        plain = np.zeros(full_px, dtype=np.int32)
+        plain[:] = 1
+        g.render(frame, out=plain, stats=False)
+        torch.cuda.synchronize(dev)
+        reps = max(3, min(10, args.steps))
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            g.render(frame, out=plain, stats=False)
+        drop_ms = (time.perf_counter() - t1) / reps * 1e3
+        out["drop_in_call"] = {"ms": drop_ms, "Mrays_per_s": primary_rays / (drop_ms * 1e-3) / 1e6, "calls": reps,
+                               "equals_pipelined_frame": bool(np.array_equal(plain, last_host_frame)),
+                               "note": "blocking sr_render(scene, frame, int32* pixels, NULL) into pageable host memory: the frame is enqueued on the library's own "
+                                       "stream, every row band is copied back on a copy stream as soon as it is final, the caller's surface is pinned for the call"}
+
     extras = world == 1 and not in_library and not args.no_extras
     if extras:
         # ---- the same steps with the frame left in HBM (no read-back) ----
@@ -512,10 +529,12 @@ def main():
         #   k_shaft (packet walk)    per hit point 64 B queue record + 4 B count; per WAVE 64 B/node + 64 B/TriSlab; 4 B per list entry
         #   k_shadow (k_shadow_cls)  per hit point 64 B + 4 B + 8 B pixel RMW; per candidate 4 B list entry + 64 B TriSlab
         pkt_nodes, pkt_slabs = rs[6] - rs[14], rs[10] - rs[15]
+        # the packet walks fetch 128-byte four-wide nodes (64-byte binary nodes with --dbg 13=1, SR_DBG_BVH2_PACKETS)
+        S_PKT_NODE = 64 if any(kv.split("=")[0] == "13" and int(kv.split("=")[1]) > 0 for kv in args.dbg) else 128
         bvh_nodes = g.bvh_stats()[1] if args.mode == "bvh" else 0
         algo = {
-            "k_primary": S_PIX * npix + rs[2] * S_NODE + rs[1] * S_SLAB + rs[3] * S_TRI + 64.0 * rs[11],
-            "k_shaft": rs[11] * (64.0 + 4.0) + pkt_nodes * S_NODE + pkt_slabs * S_SLAB + rs[8] * 4.0,
+            "k_primary": S_PIX * npix + rs[2] * S_PKT_NODE + rs[1] * S_SLAB + rs[3] * S_TRI + 64.0 * rs[11],
+            "k_shaft": rs[11] * (64.0 + 4.0) + pkt_nodes * S_PKT_NODE + pkt_slabs * S_SLAB + rs[8] * 4.0,
             # one wave per hit point, every lane of a pass fetches its own node / TriSlab: the same records are touched again and again by
             # different hit points, but one launch need not move a record more than once -- capped at the arrays' sizes
             "k_shaft_round2": min(rs[14] * S_NODE + rs[15] * S_SLAB, float(bvh_nodes * S_NODE + args.tris * S_SLAB)),

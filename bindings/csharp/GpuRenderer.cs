@@ -107,9 +107,20 @@ namespace Engine3D.Hip
     {
         public const uint F_SHADING = 1, F_SHADOWS = 2, F_FOCAL_BLUR = 4, F_POINT_LIGHT = 8, F_SPECULAR = 16, F_STATIC_SHADOWS = 32;
         public const int MODE_REF_TREE = 0, MODE_BRUTE = 1, MODE_BVH = 2;
+        /// Models with at least this many triangles are traced through the library's own BVH when the caller asked for the
+        /// subdivided path (rayTraceSubdivision): same pixels (include/softray.h SR_MODE_BVH), 10x faster soft shadows -- the
+        /// reference's 15-level tree holds >= 60 triangles per leaf at 1 M triangles.  int.MaxValue keeps every model on the
+        /// literal reference tree.
+        public int OwnBvhThreshold = 5000;
+        /// false (default): Render() does not ask for the three traversal counters (NumGeometryTests / NumNodeVisits /
+        /// NumLeafNodeVisits read 0, NumRaysFired is computed on the host), which lets the library use the own BVH and answer a
+        /// reference-tree frame's shadow rays on it.  true: the literal reference-tree traversal with the reference's counters.
+        public bool LiteralTraversalCounters = false;
         IntPtr scene;
         Model uploaded;                  // the model whose triangles the scene holds
         uint builtModes;                 // structures built for `uploaded` (bit 1 << mode)
+        SrFrame frame;                   // reused from call to call: its arrays are allocated once
+        bool frameReady;
         int offsetsSeed;                 // seed areaLightOffsets was generated with
         double[] areaLightOffsets;       // new Random(rayTraceRandomSeed): ShadowMethod.cs:63-73
         GCHandle offsetsPin;
@@ -154,11 +165,23 @@ namespace Engine3D.Hip
                 builtModes = 0;
             }
             uint bit = 1u << mode;
-            if (mode != MODE_BRUTE && (builtModes & bit) == 0)
+            if (mode == MODE_REF_TREE && UsesOwnBvh(model)) bit = 1u << MODE_BVH;                    // large model: only the own BVH is needed
+            else if (mode == MODE_REF_TREE && !LiteralTraversalCounters) bit |= 1u << MODE_BVH;      // shadow rays of a tree frame take the shaft path
+            if (mode != MODE_BRUTE && (builtModes & bit) != bit)
             {
-                Native.Check(Native.sr_build(scene, bit, 0, 0));                                     // SpatialSubdivision defaults 15 / 25
+                Native.Check(Native.sr_build(scene, bit & ~builtModes, 0, 0));                       // SpatialSubdivision defaults 15 / 25
                 builtModes |= bit;
             }
+        }
+
+        bool UsesOwnBvh(Model model) { return !LiteralTraversalCounters && model.Triangles.Count >= OwnBvhThreshold; }
+
+        /// The trace mode Render() should be given for `rayTraceSubdivision`: the reference tree (literal) or, for large models,
+        /// the library's own BVH.
+        public int TraceMode(bool rayTraceSubdivision)
+        {
+            if (!rayTraceSubdivision) return MODE_BRUTE;
+            return (uploaded != null && UsesOwnBvh(uploaded)) ? MODE_BVH : MODE_REF_TREE;
         }
 
         /// ExtraGeometryToRaytrace (Renderer.cs:460, 1545-1549): the collection is scanned first to last BEFORE the model, with
@@ -218,20 +241,30 @@ namespace Engine3D.Hip
                 offsetsPin = GCHandle.Alloc(areaLightOffsets, GCHandleType.Pinned);
                 offsetsSeed = randomSeed;
             }
-            var f = new SrFrame
+            if (!frameReady)
             {
-                width = width, height = height, start_row = startRow, end_row = endRow, sub_pixel_res = subPixelRes,
-                background_argb = backgroundColor, flags = flags, random_seed = randomSeed, shadow_samples = 0, trace_mode = mode,
-                concurrency = concurrency,                                   // rayTraceConcurrency: fill order of the static shadow cache
-                transform = new double[12], inv_transform = new double[12],
-                position_z = instance.Position.z, fov_depth = fieldOfViewDepth, focal_depth = focalDepth,
-                focal_blur_strength = focalBlurStrength, ambient = ambient, shininess = shininess,
-                light_dir_view = new[] { lightDirView.x, lightDirView.y, lightDirView.z },
-                light_pos_view = new[] { lightPosView.x, lightPosView.y, lightPosView.z },
-                area_light_offsets = offsetsPin.AddrOfPinnedObject()
-            };
-            for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { f.transform[4 * r + c] = transform[r, c]; f.inv_transform[4 * r + c] = inverseTransform[r, c]; }
-            Native.Check(Native.sr_render(scene, ref f, pixels, stats4), renderCall: true);   // blocking; `pixels` is only touched during the call
+                frame = new SrFrame { transform = new double[12], inv_transform = new double[12], light_dir_view = new double[3], light_pos_view = new double[3] };
+                frameReady = true;
+            }
+            frame.width = width; frame.height = height; frame.start_row = startRow; frame.end_row = endRow; frame.sub_pixel_res = subPixelRes;
+            frame.background_argb = backgroundColor; frame.flags = flags; frame.random_seed = randomSeed; frame.shadow_samples = 0; frame.trace_mode = mode;
+            frame.concurrency = concurrency;                                 // rayTraceConcurrency: fill order of the static shadow cache
+            frame.position_z = instance.Position.z; frame.fov_depth = fieldOfViewDepth; frame.focal_depth = focalDepth;
+            frame.focal_blur_strength = focalBlurStrength; frame.ambient = ambient; frame.shininess = shininess;
+            frame.light_dir_view[0] = lightDirView.x; frame.light_dir_view[1] = lightDirView.y; frame.light_dir_view[2] = lightDirView.z;
+            frame.light_pos_view[0] = lightPosView.x; frame.light_pos_view[1] = lightPosView.y; frame.light_pos_view[2] = lightPosView.z;
+            frame.area_light_offsets = offsetsPin.AddrOfPinnedObject();
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { frame.transform[4 * r + c] = transform[r, c]; frame.inv_transform[4 * r + c] = inverseTransform[r, c]; }
+            // blocking; `pixels` is only touched during the call (the library pins it for the call and copies row bands into it while
+            // later bands still render).  Without LiteralTraversalCounters no counters are asked for: stats4 gets the rays fired only
+            ulong[] counters = LiteralTraversalCounters ? stats4 : null;
+            Native.Check(Native.sr_render(scene, ref frame, pixels, counters), renderCall: true);
+            if (!LiteralTraversalCounters && stats4 != null)
+            {
+                int a = Math.Min(Math.Max(0, startRow), height - 1), b = Math.Min(Math.Max(0, endRow), height - 1);   // Renderer.cs:1652-1653
+                stats4[0] = b < a ? 0UL : (ulong)(b - a + 1) * (ulong)width * (ulong)(subPixelRes * subPixelRes);       // NumRaysFired (:1916)
+                stats4[1] = stats4[2] = stats4[3] = 0;
+            }
         }
 
         /// A new Renderer starts with an empty static shadow cache (ShadowMethod.cs:75-83)

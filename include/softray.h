@@ -307,8 +307,8 @@ int  sr_anti_alias_device(sr_scene*, const void* d_src, int32_t dst_width, int32
  * schedule with the host's env.  value < 0 restores the default.  Used by tests/ and scripts/ only. */
 enum {
     SR_DBG_BAND_SAMPLES   = 0,   /* samples per row band (default 16 Mi / 32 Mi): small values force several bands             */
-    SR_DBG_ROUND_CAP0     = 1,   /* candidate-list length of shaft round 1 (default 32, <= 64)                                 */
-    SR_DBG_ROUND_CAP1     = 2,   /* ... of round 2 (default 64, <= 64): tiny lists force round 2 and the exact fallback        */
+    SR_DBG_ROUND_CAP0     = 1,   /* candidate-list length of shaft round 1 (default 40, <= 64)                                 */
+    SR_DBG_ROUND_CAP1     = 2,   /* ... of round 2 (default 64, <= 1024): tiny lists force round 2 and the exact fallback      */
     SR_DBG_SPLIT          = 3,   /* concurrent part-frame pipelines (default 2, <= 4)                                          */
     SR_DBG_FB_RAY_CAP     = 4,   /* capacity of the fallback ray list                                                          */
     SR_DBG_BVH_LEAF       = 5,   /* triangles per leaf of the host SAH build (default 7, 1..15); read by the next sr_build      */
@@ -325,12 +325,17 @@ enum {
     SR_DBG_BUILD_THREADS  = 12,  /* threads of the host BVH build (default: the host's cores, at most 16); read by the next sr_build    */
     SR_DBG_BVH2_PACKETS   = 13,  /* > 0: the packet walks (k_primary, first shaft round) on the binary tree with a per-step vote instead of
                                     the four-wide tree with per-frame ordered children: same pixels; cross-check and A/B measurement */
+    SR_DBG_NO_PEER        = 14,  /* > 0 (multi-device scene): sr_render_device gathers every part's strips through pinned host staging, as it
+                                    does for a part whose memory the first device cannot read; test hook for that path                 */
+    SR_DBG_LITERAL_SHADOWS = 15, /* > 0: no shortcut for ShadowMethod -- a directional light's samples are traced one by one although all of
+                                    them provably escape, and a SR_MODE_REF_TREE frame traces its shadow rays through the reference tree
+                                    even when the caller does not ask for the traversal counters; cross-checks of both shortcuts      */
     SR_DBG_COUNT          = 16
 };
 int  sr_debug_set(sr_scene*, int32_t key, int64_t value);
 
 /* Diagnostics only: the pipeline's device counters of the last frame, summed over its concurrent part-frame pipelines (last row band of each)
- * {hit points queued, per-lane shadow work head, hit points that needed the long (round-2) candidate list,
+ * {hit-queue entries (on the shaft path: the padded tile-queue slot count, not the hits), per-lane shadow work head, hit points that needed the long (round-2) candidate list,
  *  hit points sent to the exact per-lane fallback, fallback work head, 0, 0, 0}. */
 int  sr_debug_counters(sr_scene*, uint32_t out[8]);
 

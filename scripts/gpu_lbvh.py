@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import softray_amd as sa
 import bench
+bench._imports()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 extent = float(sys.argv[2]) if len(sys.argv) > 2 else 0.05
 args = bench.argparse.Namespace(res=4096, tris=n, shadows=100, spp=1, mode="bvh", depth=1.5, extent=extent, bounces=0,

@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import softray_amd as sa
 import bench
+bench._imports()
 v9, argb = sa.make_random_triangles(1000000, 12345, space=0.95, extent=0.05, origin=-0.5, opaque=True)
 g = sa.GpuScene(0)
 g.set_triangles(v9, argb, np.array([-0.5] * 3), np.array([0.5] * 3))

@@ -5,6 +5,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import softray_amd as sa
 import bench
+bench._imports()
 args = bench.argparse.Namespace(res=4096, tris=1000000, shadows=100, spp=1, mode="bvh", depth=1.5, extent=0.05, bounces=0,
                                 reflectivity=0.0, strip_rows=16, static_shadows=False)
 v9, argb = sa.make_random_triangles(args.tris, 12345, space=1.0 - args.extent, extent=args.extent, origin=-0.5, opaque=True)

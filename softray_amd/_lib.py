@@ -35,7 +35,7 @@ SYMBOLS = [
 # sr_debug_set keys (include/softray.h)
 (DBG_BAND_SAMPLES, DBG_ROUND_CAP0, DBG_ROUND_CAP1, DBG_SPLIT, DBG_FB_RAY_CAP, DBG_BVH_LEAF, DBG_KERNEL_SWITCH,
  DBG_KERNEL_TIMING, DBG_EXACT_SHADOW_TESTS, DBG_PER_LANE_SHAFT, DBG_PER_LANE_PRIMARY, DBG_ROUND2_NODES, DBG_BUILD_THREADS,
- DBG_BVH2_PACKETS) = range(14)
+ DBG_BVH2_PACKETS, DBG_NO_PEER, DBG_LITERAL_SHADOWS) = range(16)
 
 
 class Prim(C.Structure):

@@ -68,6 +68,7 @@ struct sr_scene {
     std::vector<double>   v9;
     std::vector<uint32_t> argb;
     double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
+    double vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};   // bounds of the vertices themselves (the caller's box need not be tight, nor, in brute-force mode, contain them)
     bool have_model = false;
     std::vector<sr::Rec128> tri_recs;      // geometry_simple, Renderer.cs:1452-1469
     std::vector<sr::Rec128> extra_recs;    // ExtraGeometryToRaytrace
@@ -124,6 +125,17 @@ struct sr_scene {
     } scratch[kMaxSplit];
     hipEvent_t fork = nullptr;
     hipEvent_t multi_done = nullptr;     // (part of a multi-device scene) this part's strips of the current frame are rendered
+    // the blocking calls (sr_render) never use the null stream: frames are enqueued on io_stream, their way back to the host runs on
+    // copy_stream band by band (an event per row band: a band is copied while the next ones render)
+    hipStream_t io_stream = nullptr, copy_stream = nullptr;
+    struct BandRec { hipEvent_t ev; int band, row_begin, row_count; };
+    std::vector<hipEvent_t> band_ev_pool;
+    size_t band_ev_used = 0;
+    std::vector<BandRec> band_recs;
+    bool collect_bands = false;
+    bool can_peer = true;                // (part of a multi-device scene) the first part's device can read this part's memory
+    void* stage_host = nullptr; size_t stage_cap = 0;   // (part without peer access) pinned staging of its strips
+    hipEvent_t staged = nullptr;
     int num_cus = 0;
     bool tris_dirty = true, extra_dirty = true, ref_dirty = true, bvh_dirty = true;
     std::vector<double>  offsets_host;
@@ -292,6 +304,25 @@ int prepare_frame(sr_scene* s, const sr_frame* f, sr::FrameConst& fc) {
     return SR_OK;
 }
 
+int ensure_io_streams(sr_scene* s) {
+    if (!s->io_stream) SR_HIP(hipStreamCreateWithFlags(&s->io_stream, hipStreamNonBlocking));
+    if (!s->copy_stream) SR_HIP(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+    return SR_OK;
+}
+
+// pins the caller's (pageable) surface for the duration of one blocking call, so that the band copies are real asynchronous DMA
+// straight into it; the library does not keep the pointer.  Small frames and refusals (already registered, odd mappings) simply
+// take the runtime's pageable path.
+struct HostPin {
+    void* p = nullptr;
+    HostPin(void* ptr, size_t bytes) {
+        if (bytes < ((size_t)4 << 20)) return;
+        if (hipHostRegister(ptr, bytes, hipHostRegisterPortable) == hipSuccess) p = ptr;
+        else (void)hipGetLastError();
+    }
+    ~HostPin() { if (p) (void)hipHostUnregister(p); }
+};
+
 const int kMaxTimedLaunches = 4096;
 
 // hands out the event pair for the next launch of kernel k (nullptr once the pool is exhausted)
@@ -388,7 +419,32 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         return SR_OK;
     }
     // ---- camera-cone records of the packet primary walk: one pre-pass per (tree, ray origin) ----
-    const bool wide = f->trace_mode == SR_MODE_BVH && s->b4_num > 0 && s->dbg[SR_DBG_BVH2_PACKETS] <= 0;
+    // ---- two proofs that let a frame skip literal shadow rays without changing a byte ----
+    // (1) directional light (ShadowMethod.cs:160-166): a sample ray starts at E' + dir * 1000 + offset and runs along +dir, AWAY from
+    //     the surface point; whatever it could hit lies at least 1000 |dir| - R from E'.  When that exceeds the diagonal of everything
+    //     a hit point or a triangle can be in, no sample of no hit point is occluded: rayEscapeCount = softShadowQuality, the factor
+    //     is the constant (byte)(1.0 * 255) (applied by k_primary).  Extra geometry (unbounded planes) and the static cache (its
+    //     cells are renderer state) keep the literal path.
+    if ((fc.flags & SR_F_SHADOWS) && !(fc.flags & SR_F_POINT_LIGHT) && !static_shadows && s->extra_recs.empty() &&
+        !(f->flags & (SR_F_SINGLE_KERNEL | SR_F_PER_LANE_SHADOWS)) && f->max_bounces == 0 && s->dbg[SR_DBG_LITERAL_SHADOWS] <= 0) {
+        double diag2 = 0, len2 = 0;
+        for (int a = 0; a < 3; ++a) {
+            const double e = std::max(s->vmax[a], s->root.max[a]) - std::min(s->vmin[a], s->root.min[a]) + 0.004;   // + the probe offset, both ends
+            diag2 += e * e;
+            len2 += fc.light_dir_model[a] * fc.light_dir_model[a];
+        }
+        if (1000.0 * std::sqrt(len2) - fc.light_radius > std::sqrt(diag2) * 1.001 + 0.01) {
+            fc.flags = (fc.flags & ~(uint32_t)SR_F_SHADOWS) | sr::kFlagAllSamplesEscape;
+        }
+    }
+    // (2) a REF_TREE frame whose caller does not read the traversal counters: the shadow rays only answer "is there a hit with
+    //     rayFrac <= 1.0", which the own BVH answers identically (include/softray.h SR_MODE_BVH) -- they take the shaft path
+    const bool shadows_on_bvh = (fc.flags & SR_F_SHADOWS) && f->trace_mode == SR_MODE_REF_TREE && !d_stats && s->bvh.built && !static_shadows &&
+                                (fc.flags & SR_F_POINT_LIGHT) && fc.shadow_samples <= 128 && f->max_bounces == 0 &&
+                                !(f->flags & (SR_F_SINGLE_KERNEL | SR_F_PER_LANE_SHADOWS)) && s->dbg[SR_DBG_LITERAL_SHADOWS] <= 0;
+    if (shadows_on_bvh && (rc = sync_geometry(s, SR_MODE_BVH))) return rc;
+    const bool bvh_walks = f->trace_mode == SR_MODE_BVH || shadows_on_bvh;
+    const bool wide = bvh_walks && s->b4_num > 0 && s->dbg[SR_DBG_BVH2_PACKETS] <= 0;
     bool rewrote = false;
     auto before_rewrite = [&]() -> hipError_t {                       // frames enqueued earlier (any stream) may still read the old records
         if (rewrote || !s->pre_used_set) return hipSuccess;
@@ -442,7 +498,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     // ---- default: the primary / shadow / resolve pipeline, in row bands ----
     const long long n2 = (long long)fc.sub_pixel_res * fc.sub_pixel_res;
     const bool shadows = (fc.flags & SR_F_SHADOWS) != 0;
-    const bool shaft = shadows && f->trace_mode == SR_MODE_BVH && (fc.flags & SR_F_POINT_LIGHT) && fc.shadow_samples <= 128 &&
+    const bool shaft = shadows && bvh_walks && (fc.flags & SR_F_POINT_LIGHT) && fc.shadow_samples <= 128 &&
                        !(f->flags & SR_F_PER_LANE_SHADOWS);
     // samples per band: bounds the hit queue (64 B/sample) and, on the shaft path, the candidate lists (256 B/sample for
     // round 0 + 1/4 of the hits x 1 KB for round 1): 16 Mi samples = one 4096^2 frame = 10 GB of scratch in HBM
@@ -563,6 +619,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.per_lane_shaft = s->dbg[SR_DBG_PER_LANE_SHAFT] > 0 ? (int32_t)(s->dbg[SR_DBG_PER_LANE_SHAFT] & 3) : 0;
         P.per_lane_primary = s->dbg[SR_DBG_PER_LANE_PRIMARY] > 0;
         P.bvh2_packets = s->dbg[SR_DBG_BVH2_PACKETS] > 0;
+        P.shadows_on_bvh = shadows_on_bvh;
         P.round2_node_budget = s->dbg[SR_DBG_ROUND2_NODES] >= 0 ? (int32_t)std::min<int64_t>(s->dbg[SR_DBG_ROUND2_NODES], 1 << 30) : 0;
         P.stats = d_stats;
         P.stream = bs;
@@ -571,6 +628,18 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             hipEvent_t x = nullptr, y = nullptr;
             if (next_events((sr_scene*)user, kid, x, y) != SR_OK) { x = y = nullptr; }
             *a = x; *b = y;
+        };
+        P.band_done = nullptr;
+        if (s->collect_bands) P.band_done = [](void* user, int band, int row_begin, int row_count, hipStream_t st) {
+            sr_scene* sc = (sr_scene*)user;
+            if (sc->band_ev_used == sc->band_ev_pool.size()) {
+                hipEvent_t e = nullptr;
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { sc->collect_bands = false; return; }   // sr_render falls back to one copy
+                sc->band_ev_pool.push_back(e);
+            }
+            hipEvent_t e = sc->band_ev_pool[sc->band_ev_used++];
+            if (hipEventRecord(e, st) != hipSuccess) { sc->collect_bands = false; return; }
+            sc->band_recs.push_back({e, band, row_begin, row_count});
         };
         if (P.row_first < P.row_limit) SR_HIP(sr::launch_pipeline(P));
         if (split) {
@@ -637,7 +706,7 @@ bool multi_splittable(const sr_frame* f) { return !((f->flags & SR_F_STATIC_SHAD
 
 void clone_host_model(sr_scene* d, const sr_scene* src) {
     d->v9 = src->v9; d->argb = src->argb;
-    for (int a = 0; a < 3; ++a) { d->bmin[a] = src->bmin[a]; d->bmax[a] = src->bmax[a]; }
+    for (int a = 0; a < 3; ++a) { d->bmin[a] = src->bmin[a]; d->bmax[a] = src->bmax[a]; d->vmin[a] = src->vmin[a]; d->vmax[a] = src->vmax[a]; }
     d->have_model = src->have_model;
     d->tri_recs = src->tri_recs;
     d->root = src->root;
@@ -684,13 +753,22 @@ int sr_create_multi(const int32_t* devices, int32_t n, sr_scene** out) {
         if (rc) { for (sr_scene* q : m->parts) sr_destroy(q); delete m; return rc; }
         m->parts.push_back(part);
     }
-    // strips are gathered peer-to-peer into the first part's device (sr_render_device); a refusal only means staged copies
+    // sr_render_device gathers the strips into a surface on the first part's device: peer-to-peer where that device can read the
+    // part's memory (asked and enabled here, the answer kept per part), through pinned host staging where it cannot
     for (int i = 1; i < n; ++i) {
-        if (devices[i] == devices[0]) continue;
+        sr_scene* q = m->parts[i];
+        if (devices[i] == devices[0]) { q->can_peer = true; continue; }
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) == hipSuccess && can && hipSetDevice(devices[0]) == hipSuccess)
-            (void)hipDeviceEnablePeerAccess(devices[i], 0);
-        (void)hipGetLastError();
+        q->can_peer = false;
+        if (hipDeviceCanAccessPeer(&can, devices[0], devices[i]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        if (!can) continue;
+        hipError_t e = hipSetDevice(devices[0]);
+        if (e == hipSuccess) e = hipDeviceEnablePeerAccess(devices[i], 0);
+        if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) { q->can_peer = true; (void)hipGetLastError(); continue; }
+        // the runtime said the devices can be peers and then refused: report it instead of running with half a configuration
+        for (sr_scene* p : m->parts) sr_destroy(p);
+        delete m;
+        return hip_fail(e, "hipDeviceEnablePeerAccess");
     }
     *out = m;
     return SR_OK;
@@ -713,6 +791,11 @@ void sr_destroy(sr_scene* s) {
         for (auto& sc : s->scratch) sc.release();
         for (auto& t : s->tables) { t.dev.release(); if (t.host) (void)hipHostFree(t.host); if (t.used) (void)hipEventDestroy(t.used); }
         if (s->fork) (void)hipEventDestroy(s->fork);
+        if (s->io_stream) (void)hipStreamDestroy(s->io_stream);
+        if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+        for (hipEvent_t e : s->band_ev_pool) (void)hipEventDestroy(e);
+        if (s->stage_host) (void)hipHostFree(s->stage_host);
+        if (s->staged) (void)hipEventDestroy(s->staged);
         if (s->pre_ready) (void)hipEventDestroy(s->pre_ready);
         if (s->pre_used) (void)hipEventDestroy(s->pre_used);
         if (s->multi_done) (void)hipEventDestroy(s->multi_done);
@@ -736,6 +819,9 @@ int sr_set_triangles(sr_scene* s, const double* v9, const uint32_t* argb, int64_
     s->argb.assign(argb, argb + n);
     for (int a = 0; a < 3; ++a) { s->bmin[a] = box_min[a]; s->bmax[a] = box_max[a]; }
     s->root = sr::make_root_box(box_min, box_max);
+    for (int a = 0; a < 3; ++a) { s->vmin[a] = box_min[a]; s->vmax[a] = box_max[a]; }
+    for (int64_t i = 0; i < 3 * n; ++i)
+        for (int a = 0; a < 3; ++a) { s->vmin[a] = std::min(s->vmin[a], v9[3 * i + a]); s->vmax[a] = std::max(s->vmax[a], v9[3 * i + a]); }
     s->tri_recs.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
         const double* p = &s->v9[9 * i];
@@ -940,68 +1026,96 @@ static int multi_render(sr_scene* m, const sr_frame* f, int32_t* host_pixels, vo
     if (d_stats) return fail(SR_ERR_UNSUPPORTED, "device-side statistics are per device: use sr_render / sr_last_ray_stats with a multi-device scene");
     const int n = (int)m->parts.size();
     if (!multi_splittable(f)) {                                     // static shadow cache / caller-made strips: the first part renders it
-        return host_pixels ? sr_render(m->parts[0], f, host_pixels, stats4) : sr_render_device(m->parts[0], f, d_pixels, user_stream, nullptr);
+        rc = host_pixels ? sr_render(m->parts[0], f, host_pixels, stats4) : sr_render_device(m->parts[0], f, d_pixels, user_stream, nullptr);
+        std::memcpy(m->last_stats, m->parts[0]->last_stats, sizeof(m->last_stats));     // sr_last_ray_stats(multi scene) reports this frame
+        return rc;
     }
     if ((rc = check_mode(m->parts[0], f->trace_mode))) return rc;
     int a, b;
     clamp_rows(f, a, b);
     if (b < a) { if (stats4) std::memset(stats4, 0, 4 * sizeof(uint64_t)); return SR_OK; }
-    // ---- every part enqueues its strips on its own device (nothing below waits for the GPU until all have been enqueued) ----
+    // ---- every part enqueues its strips on its own device and stream (nothing below waits for a GPU until all have been enqueued) ----
     std::vector<sr_frame> fg(n, *f);
+    std::vector<int64_t> counts(n, 0);
     for (int g = 0; g < n; ++g) {
         sr_scene* q = m->parts[g];
-        if (m->multi_done) {                                        // the previous frame's gather may still be reading this part's strips
-            if ((rc = use_device(q))) return rc;
-            SR_HIP(hipStreamWaitEvent(nullptr, m->multi_done, 0));
-        }
         fg[g].strip_rows = kMultiStripRows; fg[g].strip_count = n; fg[g].strip_index = g;
-        const int64_t count = sr_frame_pixel_count(&fg[g]);
-        if (count == 0) continue;
+        counts[g] = sr_frame_pixel_count(&fg[g]);
+        if (counts[g] == 0) continue;
         if ((rc = check_mode(q, f->trace_mode))) return rc;
         if ((rc = use_device(q))) return rc;
-        SR_HIP(q->d_pixels.reserve((size_t)count * 4));
+        if ((rc = ensure_io_streams(q))) return rc;
+        // the previous frame's gather may still be reading this part's strips (sr_render_device returns before the copies have run)
+        if (m->multi_done) SR_HIP(hipStreamWaitEvent(q->io_stream, m->multi_done, 0));
+        SR_HIP(q->d_pixels.reserve((size_t)counts[g] * 4));
         unsigned long long* ds = nullptr;
         if (stats4) {
             SR_HIP(q->d_stats.reserve(SR_STATS_COUNT * sizeof(uint64_t)));
-            SR_HIP(hipMemsetAsync(q->d_stats.p, 0, SR_STATS_COUNT * sizeof(uint64_t), nullptr));
+            SR_HIP(hipMemsetAsync(q->d_stats.p, 0, SR_STATS_COUNT * sizeof(uint64_t), q->io_stream));
             ds = (unsigned long long*)q->d_stats.p;
         }
-        if ((rc = render_common(q, &fg[g], (uint32_t*)q->d_pixels.p, nullptr, ds))) return rc;
+        if ((rc = render_common(q, &fg[g], (uint32_t*)q->d_pixels.p, q->io_stream, ds))) return rc;
         if (!q->multi_done) SR_HIP(hipEventCreateWithFlags(&q->multi_done, hipEventDisableTiming));
-        SR_HIP(hipEventRecord(q->multi_done, nullptr));
+        SR_HIP(hipEventRecord(q->multi_done, q->io_stream));
     }
     // ---- the strips go straight to the caller's surface ----
-    for (int g = 0; g < n; ++g) {
-        sr_scene* q = m->parts[g];
-        const std::vector<StripRun> runs = strip_runs(a, b, n, g);
-        if (runs.empty()) continue;
-        if (host_pixels) {
-            if ((rc = use_device(q))) return rc;
-            SR_HIP(copy_runs(runs, n, f->width, (const uint32_t*)q->d_pixels.p, (uint32_t*)host_pixels, hipMemcpyDeviceToHost, nullptr));
-        } else {
-            if ((rc = use_device(m->parts[0]))) return rc;
-            SR_HIP(hipStreamWaitEvent(user_stream, q->multi_done, 0));
-            SR_HIP(copy_runs(runs, n, f->width, (const uint32_t*)q->d_pixels.p, (uint32_t*)d_pixels, hipMemcpyDefault, user_stream));
-        }
-    }
-    if (!host_pixels) {
-        if ((rc = use_device(m->parts[0]))) return rc;
-        if (!m->multi_done) SR_HIP(hipEventCreateWithFlags(&m->multi_done, hipEventDisableTiming));
-        SR_HIP(hipEventRecord(m->multi_done, user_stream));
-    }
     if (host_pixels) {
-        for (int k = 0; k < SR_STATS_COUNT; ++k) m->last_stats[k] = 0;
+        // every device copies its own strips over its own link, all of them at once, into the (pinned for this call) surface
+        HostPin pin(host_pixels + (size_t)a * f->width, (size_t)(b - a + 1) * f->width * 4);
         for (int g = 0; g < n; ++g) {
             sr_scene* q = m->parts[g];
+            const std::vector<StripRun> runs = strip_runs(a, b, n, g);
+            if (runs.empty() || counts[g] == 0) continue;
             if ((rc = use_device(q))) return rc;
-            SR_HIP(hipStreamSynchronize(nullptr));
-            if (stats4 && sr_frame_pixel_count(&fg[g]) > 0) {
+            SR_HIP(hipStreamWaitEvent(q->copy_stream, q->multi_done, 0));
+            SR_HIP(copy_runs(runs, n, f->width, (const uint32_t*)q->d_pixels.p, (uint32_t*)host_pixels, hipMemcpyDeviceToHost, q->copy_stream));
+        }
+        for (int k = 0; k < SR_STATS_COUNT; ++k) m->last_stats[k] = 0;
+        for (int g = 0; g < n; ++g) {                               // one wait per device, after everything has been queued
+            sr_scene* q = m->parts[g];
+            if (counts[g] == 0) continue;
+            if ((rc = use_device(q))) return rc;
+            SR_HIP(hipStreamSynchronize(q->copy_stream));
+            SR_HIP(hipStreamSynchronize(q->io_stream));
+            if (stats4) {
                 SR_HIP(hipMemcpy(q->last_stats, q->d_stats.p, SR_STATS_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));
                 for (int k = 0; k < SR_STATS_COUNT; ++k) m->last_stats[k] += q->last_stats[k];
             }
         }
         if (stats4) std::memcpy(stats4, m->last_stats, 4 * sizeof(uint64_t));
+        return SR_OK;
     }
+    // device surface on the first part's device: peer-to-peer over xGMI where the first device can read the part's memory,
+    // through pinned host staging where it cannot (sr_create_multi asked; nothing is assumed)
+    for (int g = 0; g < n; ++g) {
+        sr_scene* q = m->parts[g];
+        const std::vector<StripRun> runs = strip_runs(a, b, n, g);
+        if (runs.empty() || counts[g] == 0) continue;
+        if (q->can_peer && q->dbg[SR_DBG_NO_PEER] <= 0) {
+            if ((rc = use_device(m->parts[0]))) return rc;
+            SR_HIP(hipStreamWaitEvent(user_stream, q->multi_done, 0));
+            SR_HIP(copy_runs(runs, n, f->width, (const uint32_t*)q->d_pixels.p, (uint32_t*)d_pixels, hipMemcpyDefault, user_stream));
+        } else {
+            const size_t bytes = (size_t)counts[g] * 4;
+            if ((rc = use_device(q))) return rc;
+            if (bytes > q->stage_cap) {
+                if (q->stage_host) SR_HIP(hipHostFree(q->stage_host));
+                q->stage_host = nullptr; q->stage_cap = 0;
+                SR_HIP(hipHostMalloc(&q->stage_host, bytes, hipHostMallocPortable));
+                q->stage_cap = bytes;
+            }
+            if (!q->staged) SR_HIP(hipEventCreateWithFlags(&q->staged, hipEventDisableTiming));
+            SR_HIP(hipStreamWaitEvent(q->copy_stream, q->multi_done, 0));
+            SR_HIP(hipMemcpyAsync(q->stage_host, q->d_pixels.p, bytes, hipMemcpyDeviceToHost, q->copy_stream));
+            SR_HIP(hipEventRecord(q->staged, q->copy_stream));
+            if ((rc = use_device(m->parts[0]))) return rc;
+            SR_HIP(hipStreamWaitEvent(user_stream, q->staged, 0));
+            SR_HIP(copy_runs(runs, n, f->width, (const uint32_t*)q->stage_host, (uint32_t*)d_pixels, hipMemcpyHostToDevice, user_stream));
+        }
+    }
+    if ((rc = use_device(m->parts[0]))) return rc;
+    if (!m->multi_done) SR_HIP(hipEventCreateWithFlags(&m->multi_done, hipEventDisableTiming));
+    SR_HIP(hipEventRecord(m->multi_done, user_stream));
     return SR_OK;
 }
 
@@ -1037,23 +1151,47 @@ int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]
         if (b < a || count == 0) { if (stats) std::memset(stats, 0, 4 * sizeof(uint64_t)); return SR_OK; }   // rayTraceStartRow > EndRow: nothing is drawn
     }
     SR_HIP(s->d_pixels.reserve((size_t)count * 4));
+    if ((rc = ensure_io_streams(s))) return rc;
     unsigned long long* d_stats = nullptr;
     if (stats) {
         SR_HIP(s->d_stats.reserve(SR_STATS_COUNT * sizeof(uint64_t)));
-        SR_HIP(hipMemsetAsync(s->d_stats.p, 0, SR_STATS_COUNT * sizeof(uint64_t), nullptr));
+        SR_HIP(hipMemsetAsync(s->d_stats.p, 0, SR_STATS_COUNT * sizeof(uint64_t), s->io_stream));
         d_stats = (unsigned long long*)s->d_stats.p;
     }
-    if ((rc = render_common(s, f, (uint32_t*)s->d_pixels.p, nullptr, d_stats))) return rc;
-    SR_HIP(hipStreamSynchronize(nullptr));
-    // only the rows the reference would have drawn are copied back into the caller's surface
-    if (f->strip_count > 0) {
-        if (count > 0) SR_HIP(hipMemcpy(pixels, s->d_pixels.p, (size_t)count * 4, hipMemcpyDeviceToHost));
+    // rows the reference would have drawn: [a, b] of the surface, or this call's strips as one compact block
+    int a, b;
+    clamp_rows(f, a, b);
+    const bool strips = f->strip_count > 0;
+    const size_t first_px = strips ? 0 : (size_t)a * f->width;
+    const size_t total_px = strips ? (size_t)count : (size_t)(b - a + 1) * f->width;
+    HostPin pin(pixels + first_px, total_px * 4);                  // (hidden behind the frame: nothing has been enqueued yet that we wait for)
+    // ---- enqueue the frame; every row band leaves an event behind ----
+    s->band_recs.clear();
+    s->band_ev_used = 0;
+    s->collect_bands = true;
+    rc = render_common(s, f, (uint32_t*)s->d_pixels.p, s->io_stream, d_stats);
+    const bool banded = s->collect_bands && !s->band_recs.empty();
+    s->collect_bands = false;
+    if (rc) { (void)hipStreamSynchronize(s->io_stream); return rc; }
+    // ---- its way back: band by band on the copy stream, earliest bands first (the two half-frame pipelines run side by side) ----
+    size_t covered = 0;
+    if (banded) {
+        std::stable_sort(s->band_recs.begin(), s->band_recs.end(), [](const sr_scene::BandRec& x, const sr_scene::BandRec& y) { return x.band < y.band; });
+        for (const sr_scene::BandRec& r : s->band_recs) covered += (size_t)r.row_count * f->width;
+    }
+    if (banded && covered == total_px) {
+        for (const sr_scene::BandRec& r : s->band_recs) {
+            const size_t off = first_px + (size_t)r.row_begin * f->width, n = (size_t)r.row_count * f->width;
+            SR_HIP(hipStreamWaitEvent(s->copy_stream, r.ev, 0));
+            SR_HIP(hipMemcpyAsync(pixels + off, (const int32_t*)s->d_pixels.p + off, n * 4, hipMemcpyDeviceToHost, s->copy_stream));
+        }
+        SR_HIP(hipStreamSynchronize(s->copy_stream));
+        SR_HIP(hipStreamSynchronize(s->io_stream));                 // (the join of the halves, the statistics)
     } else {
-        int a, b;
-        clamp_rows(f, a, b);
-        size_t off = (size_t)a * f->width;
-        size_t n = (size_t)(b - a + 1) * f->width;
-        SR_HIP(hipMemcpy(pixels + off, (const int32_t*)s->d_pixels.p + off, n * 4, hipMemcpyDeviceToHost));
+        // one-kernel frames (no bands): the whole range after the frame
+        SR_HIP(hipStreamSynchronize(s->io_stream));
+        SR_HIP(hipMemcpyAsync(pixels + first_px, (const int32_t*)s->d_pixels.p + first_px, total_px * 4, hipMemcpyDeviceToHost, s->copy_stream));
+        SR_HIP(hipStreamSynchronize(s->copy_stream));
     }
     if (stats) {
         SR_HIP(hipMemcpy(s->last_stats, s->d_stats.p, SR_STATS_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost));

@@ -90,11 +90,15 @@ struct PipelineLaunch {
     int32_t     round2_node_budget; // later shaft rounds: a private walk gives up after this many nodes (0 = never)
     bool        per_lane_primary; // k_primary with private walks instead of the packet walk + camera-cone filter (cross-check)
     bool        bvh2_packets;     // the packet walks on the two-wide tree with a per-step vote (round 2's kernels; cross-check)
+    bool        shadows_on_bvh;   // mode != BVH: the shadow rays of a dynamic frame are traced on the own BVH (shaft path) all the same
     int32_t     per_lane_shaft;   // bit 0: k_shaft (private walks) for the first round instead of k_shaft_pkt, bit 1: for the later rounds instead of k_shaft_coop (cross-checks)
     bool        exact_shadow_tests; // k_shadow_test (every pair in FP64) instead of k_shadow_cls (fp32 classification first)
     unsigned long long* stats;  // device [8] or nullptr
     hipStream_t stream;
     void (*get_events)(void* user, int kernel_id, hipEvent_t* start, hipEvent_t* stop);   // optional per-launch timing
+    // optional: called when every kernel of a row band has been enqueued on `stream` -- compact rows [row_begin, row_begin + row_count)
+    // of the frame are final once what is on the stream now has run (sr_render copies a band to the host while the next ones render)
+    void (*band_done)(void* user, int band_index, int row_begin, int row_count, hipStream_t stream);
     void*       user;
 };
 hipError_t launch_pipeline(const PipelineLaunch& L);

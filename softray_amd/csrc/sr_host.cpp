@@ -1,10 +1,14 @@
 // sr_host.cpp -- host-side scene preparation (see sr_host.h).  Compile with -ffp-contract=off.
 #include "sr_host.h"
 
+#include <sched.h>
+
 #include <algorithm>
 #include <array>
 #include <cfloat>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <atomic>
@@ -443,6 +447,25 @@ struct BvhBuilder {
 };
 }  // namespace
 
+// cores this process may actually use: its affinity mask, capped by the cgroup's CPU quota (a shared GPU box gives every job a
+// share; hardware_concurrency() would report the whole machine and oversubscribe it)
+static int usable_cores() {
+    int cores = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) cores = std::min(cores, c); }
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        long long per = 0;
+        if (std::fscanf(f, "%63s %lld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) {
+            const long long quota = std::atoll(q);
+            if (quota > 0) cores = (int)std::max<long long>(1, std::min<long long>(cores, (quota + per - 1) / per));
+        }
+        std::fclose(f);
+    }
+    return cores;
+}
+
 void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int leaf_max, int threads) {
     out = Bvh();
     size_t n = v9.size() / 9;
@@ -450,7 +473,7 @@ void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int
     for (int a = 0; a < 3; ++a) ext = std::max(ext, root.max[a] - root.min[a]);
     BvhBuilder bb(out, root, std::ldexp(ext > 0 ? ext : 1.0, -16));
     bb.kLeafMax = std::min(15, std::max(1, leaf_max));
-    if (threads <= 0) threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (threads <= 0) threads = std::min(16, usable_cores());
     bb.threads = n > (size_t)2 * BvhBuilder::kTaskSize ? std::max(1, std::min(threads, (int)BvhBuilder::kMaxThreads)) : 1;
     bb.buf[0].resize(n);
     bb.buf[1].resize(n);

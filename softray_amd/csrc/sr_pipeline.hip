@@ -139,6 +139,8 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
         if (live) {
             uint32_t color = fc.background;
             if (ok) color = (fc.flags & 1u) ? shade(fc, h.pos, h.nrm, h.color) : h.color;
+            // ShadowMethod with rayEscapeCount == softShadowQuality for every hit point (proven on the host): (byte)(1.0 * 255)
+            if (ok && (fc.flags & kFlagAllSamplesEscape)) color = modulate(color, to_byte((double)fc.shadow_samples / (double)fc.shadow_samples * 255));
             samples[sbase + si] = color;
             if (bounce) {                                                    // level 0 of the mirror chain (see k_bounce)
                 bounce_nlev[sbase + si] = ok ? 1 : 0;
@@ -883,8 +885,8 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc
 // the candidate lists may differ in order and in which candidates a truncated list holds, which no later stage depends on.
 // LDS per wave: [levels] node words + [levels][64] 16-bit bounds, levels = 3 * b4depth + 2.
 // --------------------------------------------------------------------------------------------------
-template <bool STATS>
-__global__ __launch_bounds__(256, 7) void k_shaft_pkt4(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
+template <bool STATS, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
                                                     const unsigned int* __restrict__ hit_count, int cap, int levels, int tile_n2, int tile_rows,
                                                     unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
                                                     uint32_t* __restrict__ samples, unsigned int* __restrict__ work_count,
@@ -956,14 +958,11 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt4(DevScene sc, FrameConst f
         b0 = fminf(b0, nu); b1 = fminf(b1, nu); b2 = fminf(b2, nu); b3 = fminf(b3, nu);
         const bool h0 = !done && n.ch[0].n >= 0 && fmaxf(a0, umin) <= b0, h1 = !done && n.ch[1].n >= 0 && fmaxf(a1, umin) <= b1;
         const bool h2 = !done && n.ch[2].n >= 0 && fmaxf(a2, umin) <= b2, h3 = !done && n.ch[3].n >= 0 && fmaxf(a3, umin) <= b3;
-        // ---- leaf children in slot order: every interested lane filters the (broadcast) triangles with its own shaft ----
-#pragma unroll 1
-        for (int k = 0; k < 4; ++k) {
-            const int cn = pick4(k, n.ch[0].n, n.ch[1].n, n.ch[2].n, n.ch[3].n);
-            if (cn <= 0) continue;
-            const bool hc = pick4(k, h0, h1, h2, h3);
-            if (__ballot(hc && !done) == 0ull) continue;
-            const int cc = pick4(k, n.ch[0].c, n.ch[1].c, n.ch[2].c, n.ch[3].c);
+        // ---- leaf children in slot order: every interested lane filters the (broadcast) triangles with its own shaft.  Four copies of
+        //      the filter loop (one per slot, everything static) rather than one loop over a slot index: selecting a slot's count, link
+        //      and lane mask by a run-time index costs a chain of scalar branches per slot and step ----
+        const auto leaf = [&](const int cn, const int cc, const bool hc) __attribute__((always_inline)) {
+            if (__ballot(hc && !done) == 0ull) return;
             leaves++;
             slabs += (uint32_t)cn;
             for (int q = 0; q < cn; ++q) {
@@ -977,7 +976,11 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt4(DevScene sc, FrameConst f
                 umbra = umbra || (live_q && touch == 2);
                 done = done || truncated || umbra;
             }
-        }
+        };
+        if (n.ch[0].n > 0) leaf(n.ch[0].n, n.ch[0].c, h0);
+        if (n.ch[1].n > 0) leaf(n.ch[1].n, n.ch[1].c, h1);
+        if (n.ch[2].n > 0) leaf(n.ch[2].n, n.ch[2].c, h2);
+        if (n.ch[3].n > 0) leaf(n.ch[3].n, n.ch[3].c, h3);
         // ---- inner children, far to near: the nearest one a live lane wants is entered, the others wait on the stack ----
         int32_t next = -1;
         float next_u = -1.0f;
@@ -2459,8 +2462,11 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                 size_t lds = ((size_t)lv4 * 4 + (size_t)lv4 * 64 * 2) * 4;
                 const int tn2 = L.tile_queue_n2, trows = L.tile_queue_rows;
                 if (tn2 > 0) blocks = (unsigned)(xcd_tile_grid(L.fc.width, trows) * tn2);      // the grid of k_primary (x sub-samples)
-                if (L.stats) hipLaunchKernelGGL((k_shaft_pkt4<true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
-                else hipLaunchKernelGGL((k_shaft_pkt4<false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
+                const auto go = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
+                };
+                // 6 waves/SIMD (85 VGPRs): 5.16 ms on the headline frame; 7 waves (72 VGPRs, spills in the node step) 5.44; 5 waves 5.61
+                if (L.stats) go(k_shaft_pkt4<true, 6>); else go(k_shaft_pkt4<false, 6>);
             } else if (first && !(L.per_lane_shaft & 1)) {
                 // round 1 on the binary tree (cross-check): one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
                 size_t lds = ((size_t)levels * 4 + (size_t)levels * 64 * 2) * 4;
@@ -2563,7 +2569,8 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
         if (L.get_events) L.get_events(L.user, K_PRIMARY, &e0, &e1);
         if (e0) { e = hipEventRecord(e0, L.stream); if (e != hipSuccess) return e; }
         // the shaft path of a dynamic-shadow frame reads the hit queue tile by tile (k_shaft_pkt): 64-aligned entries
-        const int pad_tiles = (shadows && !(L.fc.flags & 32u) && L.fc.max_bounces == 0 && shaft_path<MODE>(L)) ? 1 : 0;
+        const bool shaft_frame = (MODE != MODE_BVH && L.shadows_on_bvh) ? shaft_path<MODE_BVH>(L) : shaft_path<MODE>(L);
+        const int pad_tiles = (shadows && !(L.fc.flags & 32u) && L.fc.max_bounces == 0 && shaft_frame) ? 1 : 0;
         e = L.fc.sub_pixel_res > 1 ? launch_primary_s<MODE, EXTRA, true>(L, row_begin, row_count, samples, pad_tiles)
                                    : launch_primary_s<MODE, EXTRA, false>(L, row_begin, row_count, samples, pad_tiles);
         if (e == hipSuccess && pad_tiles) {
@@ -2624,7 +2631,10 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
             PipelineLaunch T = L;                                    // this band's queue is tile-indexed (k_primary above)
             T.tile_queue_n2 = pad_tiles ? n2 : 0;
             T.tile_queue_rows = row_count;
-            e = launch_shadow_t<MODE, EXTRA>(T, samples, (long long)((row_count + 15) / 16 * 16) * ((L.fc.width + 15) / 16 * 16) * n2);
+            const long long max_hits = (long long)((row_count + 15) / 16 * 16) * ((L.fc.width + 15) / 16 * 16) * n2;
+            // primary rays through the reference tree / brute force, shadow rays on the own BVH (sr_api.cpp decides when that is allowed)
+            if (MODE != MODE_BVH && L.shadows_on_bvh) e = launch_shadow_t<MODE_BVH, EXTRA>(T, samples, max_hits);
+            else e = launch_shadow_t<MODE, EXTRA>(T, samples, max_hits);
             if (e != hipSuccess) return e;
         }
         if (n2 > 1) {
@@ -2638,6 +2648,7 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
             if (e != hipSuccess) return e;
             if (e1) { e = hipEventRecord(e1, L.stream); if (e != hipSuccess) return e; }
         }
+        if (L.band_done) L.band_done(L.user, (row_begin - L.row_first) / L.band_rows, row_begin, row_count, L.stream);
     }
     return hipSuccess;
 }

@@ -535,14 +535,11 @@ __device__ bool bvh4_packet_nearest(const DevScene& sc, int32_t* wnode, bool liv
             child_slabs(n.ch[3], I01, I20, I12, B0, B1, B2, t3, x3);
             const bool h0 = act && n.ch[0].n >= 0 && t0 <= x0 && x0 >= 0.0f, h1 = act && n.ch[1].n >= 0 && t1 <= x1 && x1 >= 0.0f;
             const bool h2 = act && n.ch[2].n >= 0 && t2 <= x2 && x2 >= 0.0f, h3 = act && n.ch[3].n >= 0 && t3 <= x3 && x3 >= 0.0f;
-            // ---- leaf children in slot order (front to back for this origin) ----
-#pragma unroll 1
-            for (int k = 0; k < 4; ++k) {
-                const int cn = pick4(k, n.ch[0].n, n.ch[1].n, n.ch[2].n, n.ch[3].n);
-                if (cn <= 0) continue;
-                const int cc = pick4(k, n.ch[0].c, n.ch[1].c, n.ch[2].c, n.ch[3].c);
-                const bool hc = pick4(k, h0, h1, h2, h3) && pick4(k, t0, t1, t2, t3) <= tlim;      // tlim may have shrunk in an earlier leaf
-                if (__ballot(hc) == 0ull) continue;
+            // ---- leaf children in slot order (front to back for this origin).  One copy of the triangle loop per slot, everything
+            //      static: picking a slot's count / link / lane mask by a run-time index costs a chain of scalar branches per slot ----
+            const auto leaf = [&](const int cn, const int cc, const bool h, const float t) __attribute__((always_inline)) {
+                const bool hc = h && t <= tlim;                                      // tlim may have shrunk in an earlier leaf
+                if (__ballot(hc) == 0ull) return;
                 const bool hc_first = hc && (__ffsll((long long)__ballot(hc)) - 1) == (int)(threadIdx.x & 63u);
                 for (int q = cc; q < cc + cn; ++q) {
                     bool cand = hc;
@@ -566,7 +563,11 @@ __device__ bool bvh4_packet_nearest(const DevScene& sc, int32_t* wnode, bool liv
                         }
                     }
                 }
-            }
+            };
+            if (n.ch[0].n > 0) leaf(n.ch[0].n, n.ch[0].c, h0, t0);
+            if (n.ch[1].n > 0) leaf(n.ch[1].n, n.ch[1].c, h1, t1);
+            if (n.ch[2].n > 0) leaf(n.ch[2].n, n.ch[2].c, h2, t2);
+            if (n.ch[3].n > 0) leaf(n.ch[3].n, n.ch[3].c, h3, t3);
             // ---- inner children: far to near; the nearest one some lane wants is entered, the others wait on the stack ----
             int32_t next = -1;
             if (n.ch[3].n == 0 && __ballot(h3 && t3 <= tlim) != 0ull) next = n.ch[3].c;

@@ -103,6 +103,10 @@ struct RootBox {
     double centre[3];            // (min + max) * 0.5, for the BVH's fp32 frame
 };
 
+// library-internal FrameConst.flags bit (the caller's SR_F_* bits are below 1 << 16): every area-light sample of every hit point
+// provably escapes (sr_api.cpp render_common), so ShadowMethod's factor is the constant (byte)(1.0 * 255) and no shadow ray is traced
+constexpr uint32_t kFlagAllSamplesEscape = 1u << 30;
+
 // Per-frame constants, passed by value as a kernel argument (lives in SGPRs / the kernarg segment).
 struct FrameConst {
     int32_t  width, height;

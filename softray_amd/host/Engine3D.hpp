@@ -170,8 +170,14 @@ public:
     double rayTraceFocalDepth = 1.5, rayTraceFocalBlurStrength = 10.0;
     int rayTraceConcurrency = 4, rayTraceSubPixelRes = 1, rayTraceRandomSeed = 1234567890;
     int rayTraceStartRow = 0, rayTraceEndRow = 0;
-    // MI355X additions: which structure the device walks (-1: REF_TREE if rayTraceSubdivision else BRUTE)
+    // MI355X additions: which structure the device walks (-1: chosen per model, see Mode())
     int gpuTraceMode = -1;
+    // The drop-in default is the fast path: subdivided models of >= gpuOwnBvhThreshold triangles are traced
+    // through the library's own BVH; smaller ones keep the literal reference tree for their primary rays and answer their
+    // shadow rays on the BVH.  NumGeometryTests / NumNodeVisits / NumLeafNodeVisits then read 0 (NumRaysFired is exact).
+    // gpuLiteralTraversalCounters = true: the literal tree traversal for every ray, with the reference's counters.
+    int gpuOwnBvhThreshold = 5000;
+    bool gpuLiteralTraversalCounters = false;
     int gpuMaxBounces = 0;          // config-5 extension: mirror bounces (0 = the reference's behaviour)
     double gpuReflectivity = 0.0;
     std::vector<std::shared_ptr<Instance>> Instances;
@@ -246,9 +252,11 @@ public:
             built_ = 0;
         }
         int mode = Mode();
-        if (mode != SR_MODE_BRUTE && !(built_ & (1u << mode))) {
-            sr_check(sr_build(scene_, 1u << mode, 0, 0));  // SpatialSubdivision defaults 15 / 25
-            built_ |= 1u << mode;
+        uint32_t want = mode == SR_MODE_BRUTE ? 0u : (1u << mode);
+        if (mode == SR_MODE_REF_TREE && !gpuLiteralTraversalCounters) want |= 1u << SR_MODE_BVH;   // a tree frame's shadow rays take the BVH's shaft path
+        if (want & ~built_) {
+            sr_check(sr_build(scene_, want & ~built_, 0, 0));  // SpatialSubdivision defaults 15 / 25
+            built_ |= want;
         }
     }
     void Render() {                                        // Renderer.cs:701-778
@@ -313,7 +321,12 @@ private:
         if (antiAliasResolution_ < 2) return;
         sr_check(sr_anti_alias(scene_, pixels_, aaWidth_, aaHeight_, antiAliasResolution_, aaPixels_));
     }
-    int Mode() const { return gpuTraceMode >= 0 ? gpuTraceMode : (rayTraceSubdivision ? SR_MODE_REF_TREE : SR_MODE_BRUTE); }
+    int Mode() const {
+        if (gpuTraceMode >= 0) return gpuTraceMode;
+        if (!rayTraceSubdivision) return SR_MODE_BRUTE;
+        if (!gpuLiteralTraversalCounters && model_ && (int64_t)model_->argb.size() >= gpuOwnBvhThreshold) return SR_MODE_BVH;
+        return SR_MODE_REF_TREE;
+    }
     bool PinModel() {                                      // Renderer.cs:791-810
         if (!modelVolatile_) return false;
         if (modelVolatile_->LoadingComplete) { modelVolatile_->LoadingComplete = false; model_ = modelVolatile_; return true; }
@@ -327,7 +340,14 @@ private:
         rayTraceEndRow = std::min(std::max(0, rayTraceEndRow), height_ - 1);
         sr_frame f = BuildFrame(instance);
         if (!pixels_) throw InvalidOperationException("SetRenderingSurface must be called before Render");
-        sr_check(sr_render(scene_, &f, pixels_, stats_));
+        if (gpuLiteralTraversalCounters) {
+            sr_check(sr_render(scene_, &f, pixels_, stats_));
+        } else {                                           // no counters asked for: the library may take its shortcuts
+            sr_check(sr_render(scene_, &f, pixels_, nullptr));
+            const int rows = std::max(0, rayTraceEndRow - rayTraceStartRow + 1);
+            stats_[0] = (uint64_t)rows * (uint64_t)width_ * (uint64_t)(rayTraceSubPixelRes * rayTraceSubPixelRes);   // NumRaysFired, :1916
+            stats_[1] = stats_[2] = stats_[3] = 0;
+        }
     }
 
     sr_scene* scene_ = nullptr;

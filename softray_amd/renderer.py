@@ -215,7 +215,13 @@ class Renderer:
         self.rayTraceStartRow = 0
         self.rayTraceEndRow = 0
         # MI355X additions (not in the reference): which acceleration structure the device walks
-        self.gpuTraceMode = None              # None: REF_TREE if rayTraceSubdivision else BRUTE; or MODE_BVH
+        self.gpuTraceMode = None              # None: chosen per model (see _mode); or MODE_REF_TREE / MODE_BRUTE / MODE_BVH
+        # the drop-in default is the fast path: subdivided models of >= gpuOwnBvhThreshold triangles are traced
+        # through the library's own BVH, smaller ones keep the literal reference tree for their primary rays and answer their
+        # shadow rays on the BVH; NumGeometryTests / NumNodeVisits / NumLeafNodeVisits then read 0.  True: the literal tree
+        # traversal for every ray, with the reference's counters
+        self.gpuOwnBvhThreshold = 5000
+        self.gpuLiteralTraversalCounters = False
         self.gpuTreeMaxDepth = 0              # 0 => SpatialSubdivision defaults 15 / 25
         self.gpuTreeMaxGeometryPerNode = 0
         self.gpuMaxBounces = 0                # config-5 extension: mirror bounces (0 = reference behaviour)
@@ -339,7 +345,11 @@ class Renderer:
     def _mode(self):
         if self.gpuTraceMode is not None:
             return self.gpuTraceMode
-        return MODE_REF_TREE if self.rayTraceSubdivision else MODE_BRUTE
+        if not self.rayTraceSubdivision:
+            return MODE_BRUTE
+        if not self.gpuLiteralTraversalCounters and self._model is not None and len(self._model._argb) >= self.gpuOwnBvhThreshold:
+            return MODE_BVH
+        return MODE_REF_TREE
 
     def PreCalculate(self):
         """Renderer.cs:673-699: MakeRayTracableGeometry_simple / _subdivided, here = upload + build on demand."""
@@ -353,9 +363,13 @@ class Renderer:
             self._sceneModel = m
             self._built = set()
         mode = self._mode()
-        if mode != MODE_BRUTE and mode not in self._built:
-            self._scene.build((mode,), self.gpuTreeMaxDepth, self.gpuTreeMaxGeometryPerNode)
-            self._built.add(mode)
+        want = set() if mode == MODE_BRUTE else {mode}
+        if mode == MODE_REF_TREE and not self.gpuLiteralTraversalCounters:
+            want.add(MODE_BVH)                                     # a tree frame's shadow rays take the BVH's shaft path
+        need = tuple(sorted(want - self._built))
+        if need:
+            self._scene.build(need, self.gpuTreeMaxDepth, self.gpuTreeMaxGeometryPerNode)
+            self._built.update(need)
 
     def Render(self):
         """Renderer.cs:701-778."""
@@ -456,7 +470,12 @@ class Renderer:
         self.rayTraceEndRow = min(max(0, self.rayTraceEndRow), self._height - 1)
         frame = self.BuildFrame(instance)
         view = self._pixels.reshape(-1)[: self._width * self._height]
-        _, self._stats = self._scene.render(frame, out=view, stats=True)
+        if self.gpuLiteralTraversalCounters:
+            _, self._stats = self._scene.render(frame, out=view, stats=True)
+        else:                                                      # no counters asked for: the library may take its shortcuts
+            self._scene.render(frame, out=view, stats=False)
+            rows = max(0, self.rayTraceEndRow - self.rayTraceStartRow + 1)
+            self._stats = np.array([rows * self._width * self.rayTraceSubPixelRes ** 2, 0, 0, 0], dtype=np.uint64)   # NumRaysFired, Renderer.cs:1916
 
 
 __all__ = ["Renderer", "Style", "Instance", "Model", "GeometryCollection", "Sphere", "Plane", "Triangle", "Vector", "Color",

@@ -323,6 +323,47 @@ def test_shadow_sample_variants(obj_pair):
             assert np.array_equal(got, want), (count, mode)
 
 
+def test_shadow_method_shortcuts_change_no_pixel(obj_pair):
+    """Two proofs let a frame skip literal shadow rays (sr_api.cpp render_common): every sample of a directional light escapes
+    when the model is small against the 1000-unit start offset (ShadowMethod.cs:160-166), and a SR_MODE_REF_TREE frame whose caller
+    does not read the traversal counters answers its shadow rays on the own BVH (shaft path).  Both against the literal schedule
+    (SR_DBG_LITERAL_SHADOWS), the oracle, and -- for a model 3000 units across -- the case in which proof (1) does not hold."""
+    g, o = obj_pair
+    for kw in (dict(point_light=False, shadows=True), dict(point_light=False, shadows=True, sub_pixel_res=2), dict(shadows=True),
+               dict(shadows=True, sub_pixel_res=2, focal_blur=True), dict(shadows=True, start_row=11, end_row=50)):
+        f = make_frame(88, 64, **kw)
+        want, _ = o.render(f, threads=NCPU)
+        for mode in (sa.MODE_REF_TREE, sa.MODE_BRUTE, sa.MODE_BVH):
+            fast, _ = g.render(as_sr(f, mode), stats=False)
+            g.debug_set(sa._lib.DBG_LITERAL_SHADOWS, 1)
+            literal, _ = g.render(as_sr(f, mode), stats=False)
+            g.debug_set(sa._lib.DBG_LITERAL_SHADOWS, -1)
+            with_stats, _ = g.render(as_sr(f, mode), stats=True)
+            assert np.array_equal(fast, want) and np.array_equal(literal, want) and np.array_equal(with_stats, want), (kw, mode)
+    # a random soup through the reference tree: shadow rays on the BVH (no counters asked) == literal tree == oracle
+    v9, argb, bmin, bmax = unit_cube_scene(20000)
+    g2 = sa.GpuScene(0); o2 = orc.Scene()
+    for s_ in (g2, o2):
+        s_.set_triangles(v9, argb, bmin, bmax)
+    g2.build((sa.MODE_REF_TREE, sa.MODE_BVH)); assert o2.build_tree() == 0
+    f = make_frame(120, 90, depth=1.5, shadows=True)
+    want, _ = o2.render(f, threads=NCPU)
+    assert np.array_equal(g2.render(as_sr(f, sa.MODE_REF_TREE), stats=False)[0], want)
+    assert np.array_equal(g2.render(as_sr(f, sa.MODE_REF_TREE), stats=True)[0], want)
+    # proof (1) must NOT be used for a model that reaches the 1000-unit start offset: scale the scene to 3000 units
+    scale = 3000.0
+    g3 = sa.GpuScene(0); o3 = orc.Scene()
+    for s_ in (g3, o3):
+        s_.set_triangles(v9 * scale, argb, bmin * scale, bmax * scale)
+    g3.build((sa.MODE_BVH,)); assert o3.build_tree() == 0
+    f = make_frame(64, 48, depth=1.5 * scale, shadows=True, point_light=False, mode=orc.MODE_NEAREST)
+    want, _ = o3.render(f, threads=NCPU)
+    got, _ = g3.render(as_sr(f, sa.MODE_BVH), stats=False)
+    assert np.array_equal(got, want)
+    lit = make_frame(64, 48, depth=1.5 * scale, shadows=False, point_light=False, mode=orc.MODE_NEAREST)
+    assert not np.array_equal(want, o3.render(lit, threads=NCPU)[0])        # (shadows do occur at this scale: the case is not vacuous)
+
+
 def test_pipeline_bands_rounds_and_fallback():
     """Force tiny row bands and tiny candidate lists so that a small frame goes through several bands, the second shaft
     round and the exact wave-per-hit fallback; the image must not change."""
@@ -535,12 +576,54 @@ def test_multi_device_scene_in_library():
         multi.render_device(f, out.data_ptr(), st.cuda_stream)
         torch.cuda.synchronize(dev)
         assert np.array_equal(out.cpu().numpy().view(np.uint32), want)
+        # the gather of a part whose memory the first device cannot read: through pinned host staging (hook: every part)
+        multi.debug_set(sa._lib.DBG_NO_PEER, 1)
+        out.zero_()
+        multi.render_device(f, out.data_ptr(), st.cuda_stream)
+        multi.render_device(f, out.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize(dev)
+        multi.debug_set(sa._lib.DBG_NO_PEER, -1)
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want)
+        # a large surface (the caller's buffer is pinned for the call, every device copies its strips on its own stream)
+        fl = as_sr(make_frame(1024, 1100, depth=1.5, shadows=True), sa.MODE_BVH)
+        big = np.full(1024 * 1100, 7, dtype=np.int32)
+        got_l, _ = multi.render(fl, out=big)
+        assert np.array_equal(got_l, single.render(fl)[0])
         prims = c1_spheres(4)
         multi.set_extra(prims); single.set_extra(prims)
         f = as_sr(make_frame(96, 64, depth=1.5, shadows=True), sa.MODE_BVH)
         assert np.array_equal(multi.render(f)[0], single.render(f)[0])
         single.set_extra([])
         multi.close()
+
+
+@pytest.mark.skipif(__import__("torch").cuda.device_count() < 2, reason="needs two GPUs: sr_create_multi over distinct devices (peer gather over xGMI)")
+def test_multi_device_scene_over_distinct_gpus():
+    """The cross-device path of sr_create_multi on real peers (never exercised on a one-GPU box): host surface, device surface by
+    peer-to-peer copies, and the staged gather, each against the single-GPU frame."""
+    import torch
+    ndev = min(torch.cuda.device_count(), 8)
+    v9, argb, bmin, bmax = unit_cube_scene(20000)
+    single = sa.GpuScene(0)
+    single.set_triangles(v9, argb, bmin, bmax)
+    single.build((sa.MODE_BVH,))
+    multi = sa.GpuScene(devices=list(range(ndev)))
+    multi.set_triangles(v9, argb, bmin, bmax)
+    multi.build((sa.MODE_BVH,))
+    f = as_sr(make_frame(640, 515, depth=1.5, shadows=True), sa.MODE_BVH)
+    want, _ = single.render(f)
+    assert np.array_equal(multi.render(f)[0], want)
+    dev = torch.device("cuda", 0)
+    out = torch.zeros(640 * 515, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream(dev)
+    for no_peer in (-1, 1):
+        multi.debug_set(sa._lib.DBG_NO_PEER, no_peer)
+        out.zero_()
+        multi.render_device(f, out.data_ptr(), st.cuda_stream)
+        multi.render_device(f, out.data_ptr(), st.cuda_stream)
+        torch.cuda.synchronize(dev)
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), want), no_peer
+    multi.close()
 
 
 def test_full_size_properties():

@@ -82,7 +82,10 @@ def test_RaytraceAntialised():
 def test_RaytraceDynamicShadow():
     name, got, r = RaytraceScenario(shadows=True)
     assert np.array_equal(got, golden_rgb(name, 100))
-    assert r.NumRaysFired == 10000 and r.NumNodeVisits > 0
+    assert r.NumRaysFired == 10000 and r.NumNodeVisits == 0        # default: no traversal counters asked for (fast path)
+    r.gpuLiteralTraversalCounters = True                           # the literal reference-tree traversal with the reference's counters
+    r.Render()
+    assert r.NumRaysFired == 10000 and r.NumNodeVisits > 0 and r.NumGeometryTests > 0
 
 
 @pytest.mark.gpu
