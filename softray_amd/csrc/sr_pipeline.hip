@@ -1830,6 +1830,7 @@ __global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc,
     D3 s = mk(0, 0, 0), d = mk(0, 0, 0);
     double offset = 0.0;
     f2 I01 = splat(0.0f), I20 = I01, I12 = I01, B0 = I01, B1 = I01, B2 = I01;
+    RayF rf = {};                          // fp32 pre-test frame of the ray (slab_rejects, sr_trace.h)
     float tlim = 0.0f;
     int sp = 0;
     int32_t ni = -1, leafA = -1, leafB = -1;
@@ -1868,6 +1869,7 @@ __global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc,
                                 I01 = (f2){ix, iy}; I20 = (f2){iz, ix}; I12 = (f2){iy, iz};
                                 B0 = (f2){-ox * ix, -oy * iy}; B1 = (f2){-oz * iz, -ox * ix}; B2 = (f2){-oy * iy, -oz * iz};
                                 tlim = (float)lim * kInfl + 1e-30f;
+                                rf = make_ray_f(sc, s, d);
                                 sp = 0; ni = 0; leafA = -1; leafB = -1;
                                 active = true;
                             }
@@ -1907,7 +1909,9 @@ __global__ __launch_bounds__(256) void k_shadow_rays(DevScene sc, FrameConst fc,
                 leafA = leafB;
                 leafB = -1;
                 sec.leaves++;
-                for (int k = first; k < first + cn && !blocked; ++k) {
+                // fp32 pre-test on the 64-byte records (slab_rejects); the FP64 record is fetched for the survivors only
+                for (uint32_t m = leaf_survivors(sc, first, cn, rf, tlim); m && !blocked; m &= m - 1u) {
+                    const int k = first + (__ffs((int)m) - 1);
                     double t; D3 pos;
                     sec.geom++;
                     if (tri_hit(sc.btris[k].p, s, d, t, pos) && inside(sc.root.lo, sc.root.hi, pos) && (t + offset <= 1.0)) blocked = true;
@@ -2045,6 +2049,7 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
     D3 ex_pos = mk(0, 0, 0), ex_nrm = mk(0, 0, 0);
     uint32_t ex_color = 0;
     f2 I01 = splat(0.0f), I20 = I01, I12 = I01, B0 = I01, B1 = I01, B2 = I01;
+    RayF rf = {};                              // fp32 pre-test frame of the ray (slab_rejects, sr_trace.h)
     float tlim = FLT_MAX;
     int sp = 0;
     int32_t ni = -1, leafA = -1, leafB = -1;
@@ -2093,6 +2098,7 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
                         I01 = (f2){ix, iy}; I20 = (f2){iz, ix}; I12 = (f2){iy, iz};
                         B0 = (f2){-ox * ix, -oy * iy}; B1 = (f2){-oz * iz, -ox * ix}; B2 = (f2){-oy * iy, -oz * iz};
                         tlim = FLT_MAX;
+                        rf = make_ray_f(sc, s, d);
                         sp = 0; ni = 0; leafA = -1; leafB = -1;
                     } else {
                         ni = -1; leafA = -1; leafB = -1;
@@ -2131,7 +2137,9 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
                 leafA = leafB;
                 leafB = -1;
                 sec.leaves++;
-                for (int k = first; k < first + cn; ++k) {
+                // fp32 pre-test on the 64-byte records (slab_rejects); the FP64 record is fetched for the survivors only
+                for (uint32_t m = leaf_survivors(sc, first, cn, rf, tlim); m; m &= m - 1u) {
+                    const int k = first + (__ffs((int)m) - 1);
                     const Rec128* r = &sc.btris[k];
                     double t; D3 pos;
                     sec.geom++;

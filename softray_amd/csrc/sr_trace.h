@@ -295,6 +295,63 @@ __device__ __forceinline__ void node_slabs(const BvhNode& n, f2 I01, f2 I20, f2 
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// fp32 pre-test of one (ray, triangle) pair for the PRIVATE walks (one ray per lane: k_shadow_rays, k_bounce, bvh_intersect):
+// "Triangle.IntersectRay must fail, or its hit cannot matter", decided from the triangle's 64-byte TriSlab record (unit plane
+// normal n, offset; three inward unit edge normals m_k, offsets; root-centre-relative; every value the rounding of its FP64
+// source) before the 128-byte FP64 record is touched.  With G0 = n.s - d (s = the clipped start), g1 = n.dir, K0_k = m_k.s - c_k,
+// K1_k = m_k.dir the crossing is at t_c = G0 / (-g1) and F_k there is B_k / (-g1), B_k = G0 K1_k - K0_k g1.  The reference's test
+// (Triangle.cs:83-104, Plane.cs:52-75) needs dirDist = n.dir < 0, originDist - startDist <= 0 (G(s) >= 0) and the crossing inside
+// the three edges; a caller with a distance limit (nearest hit so far / rayFrac <= 1) needs t_c below it.  Error bounds as in
+// k_shadow_cls (u = 2^-24): |G0|, |K0_k| errors < a0 = 12 u s0, |g1|, |K1_k| errors < a1 = 20 u |dir|, |B_k| error
+// < mc = |dir| (u (32 s0 + 32 (max |K0_k| + |G0|)) + 1e-9).  REJECT (the FP64 test cannot produce a hit that counts) iff
+//   g1 > 16 a1  (back-facing)   or   G0 < -a0  (start behind the plane)   or, with g1 <= -16 a1 (surely front-facing),
+//   min_k B_k < -mc  (outside an edge by > 1e-6 of the scene)   or   G0 + tlim g1 > a0 + tlim a1  (crossing beyond the limit).
+// FP64 noise is nine orders of magnitude below these margins.  A degenerate triangle's record is all zeros: never rejected.
+// --------------------------------------------------------------------------------------------------
+struct RayF {
+    f2    sdx, sdy, sdz;      // per axis (start, direction), fp32, root-centre-relative start
+    float a0, a1, glo, c0, c1;
+};
+__device__ __forceinline__ RayF make_ray_f(const DevScene& sc, D3 s, D3 d) {
+    RayF r;
+    const float ex = (float)(s.x - sc.root.centre[0]), ey = (float)(s.y - sc.root.centre[1]), ez = (float)(s.z - sc.root.centre[2]);
+    const float dx = (float)d.x, dy = (float)d.y, dz = (float)d.z;
+    r.sdx = (f2){ex, dx}; r.sdy = (f2){ey, dy}; r.sdz = (f2){ez, dz};
+    const float bx = (float)(sc.root.max[0] - sc.root.min[0]), by = (float)(sc.root.max[1] - sc.root.min[1]), bz = (float)(sc.root.max[2] - sc.root.min[2]);
+    const float s0 = (__builtin_amdgcn_sqrtf(bx * bx + by * by + bz * bz) * 0.5f + fabsf(ex) + fabsf(ey) + fabsf(ez)) * 1.002f + 0.004f;
+    const float dmax = __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * 1.0001f + 1e-30f;
+    const float u = 5.9604645e-8f;
+    r.a0 = 12.0f * u * s0;
+    r.a1 = 20.0f * u * dmax;
+    r.glo = 16.0f * r.a1;
+    r.c0 = dmax * (32.0f * u * s0 + 1e-9f);
+    r.c1 = 32.0f * u * dmax;
+    return r;
+}
+__device__ __forceinline__ bool slab_rejects(const TriSlab& t, const RayF& r, float tlim) {
+    const f2 cn = {-t.d, 0.0f}, c1 = {-t.c1, 0.0f}, c2 = {-t.c2, 0.0f}, c3 = {-t.c3, 0.0f};
+    const f2 N = pk_fma(splat(t.n[0]), r.sdx, pk_fma(splat(t.n[1]), r.sdy, pk_fma(splat(t.n[2]), r.sdz, cn)));
+    const float G0 = N.x, g1 = N.y;
+    if (g1 > r.glo || G0 < -r.a0) return true;
+    if (!(g1 <= -r.glo)) return false;                                   // grazing: the FP64 test decides
+    const f2 P = pk_fma(splat(t.m1[0]), r.sdx, pk_fma(splat(t.m1[1]), r.sdy, pk_fma(splat(t.m1[2]), r.sdz, c1)));
+    const f2 Q = pk_fma(splat(t.m2[0]), r.sdx, pk_fma(splat(t.m2[1]), r.sdy, pk_fma(splat(t.m2[2]), r.sdz, c2)));
+    const f2 T = pk_fma(splat(t.m3[0]), r.sdx, pk_fma(splat(t.m3[1]), r.sdy, pk_fma(splat(t.m3[2]), r.sdz, c3)));
+    const float B1 = __builtin_fmaf(G0, P.y, -(P.x * g1)), B2 = __builtin_fmaf(G0, Q.y, -(Q.x * g1)), B3 = __builtin_fmaf(G0, T.y, -(T.x * g1));
+    const float kmax = fmaxf(fmaxf(fabsf(P.x), fabsf(Q.x)), fabsf(T.x));
+    const float mc = __builtin_fmaf(r.c1, kmax + fabsf(G0), r.c0);
+    if (fminf(fminf(B1, B2), B3) < -mc) return true;
+    return tlim < 3.0e38f && __builtin_fmaf(tlim, g1, G0) > __builtin_fmaf(tlim, r.a1, r.a0) * 1.0001f;
+}
+// the triangles of one leaf (<= 15 records from `first`): bit k set = record first + k survives the pre-test
+__device__ __forceinline__ uint32_t leaf_survivors(const DevScene& sc, int32_t first, int32_t cn, const RayF& rf, float tlim) {
+    uint32_t m = 0u;
+    for (int k = 0; k < cn; ++k)
+        if (!slab_rejects(sc.bslab[first + k], rf, tlim)) m |= 1u << k;
+    return m;
+}
+
 template <bool ANY>
 __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out, Ctr& c) {
     D3 end = s + d * 10000.0;
@@ -316,6 +373,7 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
     }
     double best = DBL_MAX;
     int32_t bestIdx = 0x7fffffff, bestK = -1;
+    const RayF rf = make_ray_f(sc, s, d);
 
     // "while-while" traversal: a lane first walks inner nodes until it owns a pending leaf (or is finished), and only
     // then the (long, FP64) triangle tests run -- so a wavefront executes the leaf code with most lanes busy instead of
@@ -353,7 +411,9 @@ __device__ bool bvh_intersect(const DevScene& sc, Stack st, D3 s, D3 d, Hit& out
             leafA = leafB;
             leafB = -1;
             c.leaves++;
-            for (int k = first; k < first + cn; ++k) {
+            // fp32 pre-test on the 64-byte records first (slab_rejects): the FP64 record is fetched for the survivors only
+            for (uint32_t m = leaf_survivors(sc, first, cn, rf, tlim); m; m &= m - 1u) {
+                const int k = first + (__ffs((int)m) - 1);
                 const Rec128* r = &sc.btris[k];
                 double t; D3 pos;
                 c.geom++;

@@ -51,7 +51,8 @@ def RendererSetup(renderer, modelFileName, pitchDegrees, yawDegrees, rollDegrees
                                        Pitch=pitchDegrees / 180.0 * math.pi, Roll=rollDegrees / 180.0 * math.pi))
 
 
-def RaytraceScenario(shading=True, focalBlur=False, shadows=False, subPixelRes=1, resolution=100, extraGeometry=None, objectDepth=1.0):
+def RaytraceScenario(shading=True, focalBlur=False, shadows=False, subPixelRes=1, resolution=100, extraGeometry=None, objectDepth=1.0,
+                     literalCounters=False):
     from softray_amd.renderer import Renderer
     with Renderer() as renderer:
         RendererSetup(renderer, os.path.join(GOLDEN, "obj.3ds"), -22.0, 135.0, 0.0, objectDepth, resolution)
@@ -62,6 +63,7 @@ def RaytraceScenario(shading=True, focalBlur=False, shadows=False, subPixelRes=1
         renderer.rayTraceFocalDepth = objectDepth + 0.5
         renderer.rayTraceSubPixelRes = subPixelRes
         renderer.rayTraceShadows = shadows
+        renderer.gpuLiteralTraversalCounters = literalCounters
         if extraGeometry is not None:
             renderer.ExtraGeometryToRaytrace = extraGeometry
         testName = (("shading" if shading else "noShading") + ("_shadows" if shadows else "") + ("_focalBlur" if focalBlur else "") +
@@ -83,8 +85,8 @@ def test_RaytraceDynamicShadow():
     name, got, r = RaytraceScenario(shadows=True)
     assert np.array_equal(got, golden_rgb(name, 100))
     assert r.NumRaysFired == 10000 and r.NumNodeVisits == 0        # default: no traversal counters asked for (fast path)
-    r.gpuLiteralTraversalCounters = True                           # the literal reference-tree traversal with the reference's counters
-    r.Render()
+    name, got, r = RaytraceScenario(shadows=True, literalCounters=True)    # the literal reference-tree traversal with the reference's counters
+    assert np.array_equal(got, golden_rgb(name, 100))
     assert r.NumRaysFired == 10000 and r.NumNodeVisits > 0 and r.NumGeometryTests > 0
 
 
