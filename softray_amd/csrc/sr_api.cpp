@@ -109,13 +109,13 @@ struct sr_scene {
     // the short, latency-bound tail kernels of one half (second shaft round, fallback walks) overlap the other half's work
     static constexpr int kMaxSplit = 4;
     struct BandScratch {
-        DBuf hits, hits2, bounce_levels, bounce_nlev, samples, counters, fallback, fallback_state, fallback_rays, fallback_ovf;
+        DBuf hits, hits2, bounce_levels, bounce_nlev, samples, counters, fallback, fallback_state, fallback_rays, fallback_ovf, ray_sort, ray_sort_temp;
         DBuf rlist[sr::kShaftRounds], rstate[sr::kShaftRounds], rcount[sr::kShaftRounds], rcand[sr::kShaftRounds];
         hipStream_t stream = nullptr;
         hipEvent_t  done = nullptr;
         bool used_last_frame = false;
         void release() {
-            DBuf* b[] = {&hits, &hits2, &bounce_levels, &bounce_nlev, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf};
+            DBuf* b[] = {&hits, &hits2, &bounce_levels, &bounce_nlev, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf, &ray_sort, &ray_sort_temp};
             for (DBuf* x : b) x->release();
             for (int r = 0; r < sr::kShaftRounds; ++r) { rlist[r].release(); rstate[r].release(); rcount[r].release(); rcand[r].release(); }
             if (stream) (void)hipStreamDestroy(stream);
@@ -213,6 +213,7 @@ sr::DevScene dev_scene(const sr_scene* s) {
     d.bslab = (const sr::TriSlab*)s->d_bslab.p;
     d.bcam = s->cam_valid ? (const sr::CamCone*)s->d_bcam.p : nullptr;
     d.v9 = (const double*)s->d_v9.p;
+    d.b4 = s->b4_num > 0 ? (const sr::Bvh4Node*)s->d_b4.p : nullptr;
     d.b4cam = (s->b4cam_valid && s->cam_valid) ? (const sr::Bvh4Node*)s->d_b4cam.p : nullptr;
     d.b4light = s->b4light_valid ? (const sr::Bvh4Node*)s->d_b4light.p : nullptr;
     d.b4depth = s->b4_depth;
@@ -559,6 +560,9 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             SR_HIP(B.hits2.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
             SR_HIP(B.bounce_levels.reserve(idx_space * (size_t)(f->max_bounces + 1) * 4));
             SR_HIP(B.bounce_nlev.reserve(idx_space));
+            // per-level ray order (keys, sorted keys, indices, order) + the device sort's own scratch
+            SR_HIP(B.ray_sort.reserve((size_t)band_samples * 4 * 4));
+            SR_HIP(B.ray_sort_temp.reserve(sr::ray_sort_temp_bytes((unsigned)band_samples)));
         }
         if (shaft) {
             SR_HIP(B.fallback.reserve((size_t)band_samples * 4));
@@ -591,6 +595,9 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.samples = (uint32_t*)B.samples.p;
         P.hits = B.hits.p;
         P.hits2 = bounce_pipe ? B.hits2.p : nullptr;
+        P.ray_sort_buf = bounce_pipe ? (unsigned int*)B.ray_sort.p : nullptr;
+        P.ray_sort_temp = bounce_pipe ? B.ray_sort_temp.p : nullptr;
+        P.ray_sort_temp_bytes = bounce_pipe ? sr::ray_sort_temp_bytes((unsigned)band_samples) : 0;
         P.bounce_levels = bounce_pipe ? (uint32_t*)B.bounce_levels.p : nullptr;
         P.bounce_nlev = bounce_pipe ? (uint8_t*)B.bounce_nlev.p : nullptr;
         P.counters = (unsigned int*)B.counters.p;

@@ -28,6 +28,7 @@ struct DevScene {
     int32_t        bnode_bits;  // bits needed for a BVH node index (stack words pack node | bound)
     // the same tree with four children per node (packet walks), children sorted per frame: front to back for the camera rays'
     // origin / back to front for the point light (nullptr: not made -> the BVH2 packet walks run)
+    const Bvh4Node* b4;         // build order (private walks: every lane orders the children for its own ray)
     const Bvh4Node* b4cam;
     const Bvh4Node* b4light;
     int32_t        b4depth;
@@ -72,6 +73,9 @@ struct PipelineLaunch {
     unsigned int* round_cand_count[kShaftRounds]; // device per-item candidate count | truncated flag
     int32_t*      round_cand[kShaftRounds];       // device [items][pipeline_round_cap(round)] (round_cand[0] == nullptr: no shaft path)
     void*         hits2;        // second ray queue of the mirror-bounce pipeline (same size as hits)
+    unsigned int* ray_sort_buf; // mirror-bounce pipeline: 4 x band samples of scratch for the per-level ray order (nullptr: rays walk in queue order)
+    void*         ray_sort_temp;
+    size_t        ray_sort_temp_bytes;
     uint32_t*     bounce_levels; // device [band samples][max_bounces + 1]: colour of every level of a sample's mirror chain
     uint8_t*      bounce_nlev;  // device [band samples]: levels stored | 0x80 when the deepest level is a surface
     void*         static_hits;  // device HitRec[min(band samples, 128^3)]: generators of a static-shadow frame
@@ -118,6 +122,11 @@ hipError_t gather_records_device(int n, const unsigned int* d_order, const Rec12
                                  TriSlab* d_bslab, hipStream_t stream);
 hipError_t build_bvh_device(const double* d_v9, int n, const RootBox& root, const Rec128* d_tris, const TriSlab* d_slab_in,
                             BvhNode* d_nodes, Rec128* d_btris, TriSlab* d_bslab, int* num_nodes, int* depth, hipStream_t stream);
+
+// order of a bounce level's ray queue by (origin cell, direction octant) (sr_raysort.hip): order_out = permutation of [0, cap)
+size_t ray_sort_temp_bytes(unsigned int cap);
+hipError_t ray_sort(const void* queue, const unsigned int* d_count, unsigned int cap, const RootBox& root, unsigned int* keys, unsigned int* keys2,
+                    unsigned int* idx, unsigned int* order_out, void* temp, size_t temp_bytes, hipStream_t stream);
 
 // fp32 TriSlab records of n triangles (TriangleIndex order) computed on the device from the FP64 vertices (sr_lbvh.hip)
 hipError_t make_slabs_device(const double* d_v9, int n, const RootBox& root, TriSlab* d_out, hipStream_t stream);

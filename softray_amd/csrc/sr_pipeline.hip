@@ -2029,10 +2029,15 @@ __global__ __launch_bounds__(256) void k_resolve(FrameConst fc, const int32_t* _
 // Secondary rays are incoherent, so k_bounce uses persistent lanes refilled from the queue (cf. k_shadow_rays); the walk
 // is root_intersect<MODE_BVH, false, EXTRA> (extra geometry first, then bvh_intersect<false>) as a per-lane state machine.
 // --------------------------------------------------------------------------------------------------
-template <bool EXTRA, bool STATS>
+// WIDE: the private walk on the four-wide tree (build-order nodes, sc.b4): a step fetches one 128-byte node and tests four boxes,
+// the lane enters the nearest inner child it hits and stacks the others -- about half as many dependent fetches per ray as on
+// the binary tree, which is what an incoherent ray waits for (DESIGN.md "C5").  Pending leaves (up to four per step) wait in
+// registers.  Same per-ray arithmetic, same result: the nearest hit with the lowest-index tie-break is order independent.
+template <bool EXTRA, bool STATS, bool WIDE>
 __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, const HitRec* __restrict__ qin, const unsigned int* __restrict__ qin_count,
                                                 HitRec* __restrict__ qout, unsigned int* __restrict__ qout_count, unsigned int* __restrict__ head,
-                                                uint32_t* __restrict__ levels, uint8_t* __restrict__ nlev, unsigned long long* stats) {
+                                                uint32_t* __restrict__ levels, uint8_t* __restrict__ nlev, unsigned long long* stats,
+                                                const unsigned int* __restrict__ order) {
     const int tid = threadIdx.x, lane = tid & 63;
     Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
     const unsigned int total = *qin_count;
@@ -2053,6 +2058,7 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
     float tlim = FLT_MAX;
     int sp = 0;
     int32_t ni = -1, leafA = -1, leafB = -1;
+    int32_t leafC = -1, leafD = -1;            // (WIDE) a four-wide node can leave four pending leaves; the queue fills from leafA
     bool active = false, walking = false;
     bool drained = false;
     for (;;) {
@@ -2067,7 +2073,7 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
             if (!active) {
                 const unsigned int r = base + (unsigned int)__popcll(m & lanemask_lt());
                 if (r < total) {
-                    const HitRec q = qin[r];
+                    const HitRec q = qin[order ? order[r] : r];                        // (sr_raysort.hip: rays of a cell and octant side by side)
                     sample = q.sample; level = q.pad[0];
                     s0 = mk(q.pos[0], q.pos[1], q.pos[2]);
                     d = mk(q.nrm[0], q.nrm[1], q.nrm[2]);
@@ -2099,9 +2105,9 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
                         B0 = (f2){-ox * ix, -oy * iy}; B1 = (f2){-oz * iz, -ox * ix}; B2 = (f2){-oy * iy, -oz * iz};
                         tlim = FLT_MAX;
                         rf = make_ray_f(sc, s, d);
-                        sp = 0; ni = 0; leafA = -1; leafB = -1;
+                        sp = 0; ni = 0; leafA = -1; leafB = -1; leafC = -1; leafD = -1;
                     } else {
-                        ni = -1; leafA = -1; leafB = -1;
+                        ni = -1; leafA = -1; leafB = -1; leafC = -1; leafD = -1;
                     }
                     active = true;
                 }
@@ -2109,7 +2115,36 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
         }
         if (!__any(active)) break;
         if (active) {
-            while (ni >= 0 && leafA < 0) {
+            while (WIDE && ni >= 0 && leafA < 0) {
+                const Bvh4Node n = sc.b4[ni];
+                sec.nodes++;
+                // entry distance and link of every inner child the ray hits (FLT_MAX: not a candidate); leaves go to the pending queue
+                float tk[4];
+                int32_t ck[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float t, x;
+                    child_slabs(n.ch[k], I01, I20, I12, B0, B1, B2, t, x);
+                    const bool h = n.ch[k].n >= 0 && t <= x && x >= 0.0f && t <= tlim;
+                    tk[k] = (h && n.ch[k].n == 0) ? t : FLT_MAX;
+                    ck[k] = n.ch[k].c;
+                    if (h && n.ch[k].n > 0) {
+                        const int32_t v = n.ch[k].c | (n.ch[k].n << kLeafShift);
+                        if (leafA < 0) leafA = v; else if (leafB < 0) leafB = v; else if (leafC < 0) leafC = v; else leafD = v;
+                    }
+                }
+                // nearest first: a nearest-hit walk prunes with the distance of the hit it has, so the order in which the stacked
+                // subtrees come back matters (5 compare-exchanges, registers only)
+#define SR_CE(a, b) { const bool sw = tk[b] < tk[a]; const float ta = tk[a]; const int32_t ca = ck[a]; \
+                      tk[a] = sw ? tk[b] : ta; ck[a] = sw ? ck[b] : ca; tk[b] = sw ? ta : tk[b]; ck[b] = sw ? ca : ck[b]; }
+                SR_CE(0, 1) SR_CE(2, 3) SR_CE(0, 2) SR_CE(1, 3) SR_CE(1, 2)
+#undef SR_CE
+                if (tk[3] < FLT_MAX) st.put(sp++, ck[3]);         // far to near onto the stack (re-tested against tlim when popped)
+                if (tk[2] < FLT_MAX) st.put(sp++, ck[2]);
+                if (tk[1] < FLT_MAX) st.put(sp++, ck[1]);
+                ni = tk[0] < FLT_MAX ? ck[0] : ((sp > 0) ? st.get(--sp) : -1);
+            }
+            while (!WIDE && ni >= 0 && leafA < 0) {
                 const BvhNode n = sc.bnodes[ni];
                 sec.nodes++;
                 float t0, x0, t1, x1;
@@ -2135,7 +2170,8 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
             while (leafA >= 0) {
                 const int32_t first = leafA & kLeafMask, cn = (leafA >> kLeafShift) & 15;
                 leafA = leafB;
-                leafB = -1;
+                leafB = WIDE ? leafC : -1;
+                if (WIDE) { leafC = leafD; leafD = -1; }
                 sec.leaves++;
                 // fp32 pre-test on the 64-byte records (slab_rejects); the FP64 record is fetched for the survivors only
                 for (uint32_t m = leaf_survivors(sc, first, cn, rf, tlim); m; m &= m - 1u) {
@@ -2595,7 +2631,8 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
             hipEvent_t b0 = nullptr, b1 = nullptr;
             if (L.get_events) L.get_events(L.user, K_BOUNCE, &b0, &b1);         // all levels' k_bounce launches + k_fold of this band
             if (b0 && (e = hipEventRecord(b0, L.stream)) != hipSuccess) return e;
-            const size_t lds = (size_t)pipe_stack_levels(L.sc, MODE_BVH) * 256 * 4;
+            const bool wide = L.sc.b4 != nullptr && !L.bvh2_packets;                     // private walks on the four-wide tree
+            const size_t lds = (size_t)(wide ? 3 * L.sc.b4depth + 2 : pipe_stack_levels(L.sc, MODE_BVH)) * 256 * 4;
             const unsigned blocks = (unsigned)std::min<long long>((band_n + 255) / 256, (long long)L.persistent_blocks);
             int cur = 0;
             for (int level = 1; level <= L.fc.max_bounces; ++level) {
@@ -2603,8 +2640,19 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
                 if ((e = hipMemsetAsync(L.counters + 2, 0, 4, L.stream)) != hipSuccess) return e;
                 const HitRec* qin = (const HitRec*)(cur == 0 ? L.hits : L.hits2);
                 HitRec* qout = (HitRec*)(cur == 0 ? L.hits2 : L.hits);
-                if (L.stats) hipLaunchKernelGGL((k_bounce<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, qin, L.counters + cur, qout, L.counters + (1 - cur), L.counters + 2, L.bounce_levels, L.bounce_nlev, L.stats);
-                else hipLaunchKernelGGL((k_bounce<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, qin, L.counters + cur, qout, L.counters + (1 - cur), L.counters + 2, L.bounce_levels, L.bounce_nlev, L.stats);
+                // the level's rays in (origin cell, direction octant) order: neighbouring lanes walk neighbouring subtrees
+                const unsigned int* order = nullptr;
+                if (L.ray_sort_buf && L.fc.debug != 31) {
+                    const unsigned cap = (unsigned)band_n;
+                    unsigned int* b = L.ray_sort_buf;
+                    if ((e = ray_sort(qin, L.counters + cur, cap, L.sc.root, b, b + (size_t)cap, b + 2 * (size_t)cap, b + 3 * (size_t)cap, L.ray_sort_temp, L.ray_sort_temp_bytes, L.stream)) != hipSuccess) return e;
+                    order = b + 3 * (size_t)cap;
+                }
+                const auto go = [&](auto kern) {
+                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, qin, L.counters + cur, qout, L.counters + (1 - cur), L.counters + 2, L.bounce_levels, L.bounce_nlev, L.stats, order);
+                };
+                if (wide) { if (L.stats) go(k_bounce<EXTRA, true, true>); else go(k_bounce<EXTRA, false, true>); }
+                else { if (L.stats) go(k_bounce<EXTRA, true, false>); else go(k_bounce<EXTRA, false, false>); }
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 cur = 1 - cur;
             }

@@ -2,6 +2,7 @@
 same inputs and against the reference's golden BMPs.  Bar: bit-exact ARGB / bit-exact doubles."""
 import math
 import os
+import time
 
 import numpy as np
 import pytest
@@ -659,10 +660,24 @@ def test_full_size_properties():
     o = orc.Scene()
     o.set_triangles(v9, argb, bmin, bmax)
     assert o.build_tree() == 0
-    for r0 in (2047, 611, 1313, 2790, 3402):             # row pairs spread over the frame (object centre, silhouettes, seams of the halves)
+    # three fixed row pairs (object centre, a silhouette, the seam of the two half-frame pipelines) + two that ROTATE: drawn from a seed
+    # that changes every day (SOFTRAY_TEST_SEED pins it) and is printed, so that successive runs cover new pixels of the frame
+    seed = int(os.environ.get("SOFTRAY_TEST_SEED", str(int(time.time()) // 86400)))
+    rot = [int(x) for x in np.random.RandomState(seed).randint(300, 3700, size=2)]       # (rows that cross the object)
+    print("test_full_size_properties: SOFTRAY_TEST_SEED=%d -> rotating row pairs %s" % (seed, rot))
+    for r0 in [2047, 611, 2790] + rot:
         fo = make_frame(4096, depth=1.5, shadows=True, start_row=r0, end_row=r0 + 1)
         want, _ = o.render(fo, threads=NCPU)
-        assert np.array_equal(want.reshape(4096, 4096)[r0:r0 + 2], a2[r0:r0 + 2]), r0
+        assert np.array_equal(want.reshape(4096, 4096)[r0:r0 + 2], a2[r0:r0 + 2]), (r0, seed)
+    # (c2) config C3's own resolution (2048^2, shading + 100-sample shadows): rendering is idempotent, two row pairs equal the oracle
+    f3 = make_frame(2048, depth=1.5, shadows=True)
+    c3, _ = g.render(as_sr(f3, sa.MODE_BVH))
+    assert np.array_equal(c3, g.render(as_sr(f3, sa.MODE_BVH), stats=False)[0])
+    c3 = c3.reshape(2048, 2048)
+    for r0 in (1023, 300 + rot[0] // 3):
+        fo = make_frame(2048, depth=1.5, shadows=True, start_row=r0, end_row=r0 + 1)
+        want, _ = o.render(fo, threads=NCPU)
+        assert np.array_equal(want.reshape(2048, 2048)[r0:r0 + 2], c3[r0:r0 + 2]), ("C3", r0, seed)
     # (d) static shadow cache at 4096^2: a warm cache reproduces the frame (every cell it needs exists), shadow-less pixels are
     #     untouched, and every shadowed pixel is its shaded colour modulated by SOME cache byte 1..255
     fs = make_frame(4096, depth=1.5, shadows=True, static_shadows=True)
