@@ -236,7 +236,8 @@ def main():
     ap.add_argument("--reflectivity", type=float, default=0.5)
     ap.add_argument("--extent", type=float, default=0.05, help="triangle extent of the synthetic soup (SURVEY 8d: 0.05 at 1M, 0.02 at 10M)")
     ap.add_argument("--strip-rows", type=int, default=16)
-    ap.add_argument("--device-build", action="store_true", help="build the BVH on the GPU (LBVH) instead of the host SAH builder")
+    ap.add_argument("--device-build", action="store_true", help="(the default since round 3) build the BVH on the GPU (LBVH)")
+    ap.add_argument("--host-build", action="store_true", help="build the BVH with the host's binned-SAH builder instead of the device LBVH")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary measurements (kernel times, counters, primary-only, surface passes)")
     ap.add_argument("--exact-shadow-tests", action="store_true", help="k_shadow_test (every pair in FP64) instead of the fp32-classified k_shadow_cls")
@@ -304,7 +305,7 @@ def main():
         g.debug_set(int(k), int(v))
     t0 = time.time()
     g.build(({"bvh": sa.MODE_BVH, "ref": sa.MODE_REF_TREE}.get(args.mode),) if args.mode != "brute" else (),
-            on_device=args.device_build and args.mode == "bvh")
+            on_device=(False if args.host_build else None) if args.mode == "bvh" else None)
     build_s = time.time() - t0
 
     n_gpus = args.gpus if (world > 1 or in_library) else 1

@@ -21,6 +21,7 @@ F_NO_SPLIT = 1 << 10
 MODE_REF_TREE, MODE_BRUTE, MODE_BVH = 0, 1, 2
 TARGET_ROOT = 0x100
 BUILD_ON_DEVICE = 0x100
+BUILD_ON_HOST = 0x200
 STYLE_STANDARD, STYLE_COLOR_SHUFFLE, STYLE_NEGATIVE, STYLE_DEPTH_SMOOTH, STYLE_DEPTH_BANDED = 0, 1, 2, 3, 4
 
 # every symbol include/softray.h declares (tests/test_abi.py checks the header against this list)

@@ -884,7 +884,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         int rc = sr_build(s->parts[0], modes, max_depth, max_per_leaf);
         for (size_t i = 1; i < s->parts.size() && !rc; ++i) {
             sr_scene* q = s->parts[i];
-            if ((modes & SR_BUILD_ON_DEVICE) && (modes & (1u << SR_MODE_BVH))) {
+            if (!(modes & SR_BUILD_ON_HOST) && (modes & (1u << SR_MODE_BVH)) && s->parts[0]->bvh_on_device) {
                 q->ref = s->parts[0]->ref; q->ref_dirty = true;
                 rc = sr_build(q, modes & ~(1u << SR_MODE_REF_TREE), max_depth, max_per_leaf);
                 if (!rc && (modes & (1u << SR_MODE_REF_TREE)) && (rc = use_device(q)) == SR_OK) rc = sync_geometry(q, SR_MODE_REF_TREE);
@@ -910,10 +910,12 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
             return fail(SR_ERR_OUT_OF_RANGE, "A triangle vertex is outside the bounding box");
         s->ref_dirty = true;
     }
-    const bool on_device = (modes & SR_BUILD_ON_DEVICE) != 0 && s->argb.size() > 64;
+    // the own BVH is built where the triangles are: on the device (LBVH, sr_lbvh.hip), unless the scene has none, is tiny, or the
+    // caller asks for the host's binned-SAH builder (SR_BUILD_ON_HOST)
+    if ((modes & SR_BUILD_ON_DEVICE) && s->device < 0) return fail(SR_ERR_NO_DEVICE, "SR_BUILD_ON_DEVICE needs a HIP device");
+    const bool on_device = s->device >= 0 && !(modes & SR_BUILD_ON_HOST) && s->argb.size() > 64;
     if ((modes & (1u << SR_MODE_BVH)) && on_device) {
         // ---- LBVH built by the GPU (sr_lbvh.hip) ----
-        if (s->device < 0) return fail(SR_ERR_NO_DEVICE, "SR_BUILD_ON_DEVICE needs a HIP device");
         int rc = use_device(s);
         if (rc) return rc;
         if ((rc = sync_geometry(s, SR_MODE_BRUTE))) return rc;            // d_tris
@@ -938,10 +940,17 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         s->bvh_on_device = true;
         s->bvh_dirty = false;
         s->cam_valid = false;
-        {   // the four-wide tree is collapsed on the host from a copy of the device-built nodes
-            std::vector<sr::BvhNode> tmp((size_t)nn);
-            SR_HIP(hipMemcpy(tmp.data(), s->d_bnodes.p, (size_t)nn * sizeof(sr::BvhNode), hipMemcpyDeviceToHost));
-            if ((rc = upload_wide_tree(s, tmp.data(), tmp.size()))) return rc;
+        {   // the four-wide tree of the packet walks, collapsed where the binary nodes are
+            if (s->pre_used_set) SR_HIP(hipEventSynchronize(s->pre_used));      // a frame in flight may still be walking the old tree's copies
+            s->b4cam_valid = s->b4light_valid = false;
+            SR_HIP(s->d_b4.reserve((size_t)nn * sizeof(sr::Bvh4Node)));
+            int n4 = 0, d4 = 0;
+            e = sr::collapse_bvh4_device((const sr::BvhNode*)s->d_bnodes.p, nn, (sr::Bvh4Node*)s->d_b4.p, &n4, &d4, nullptr);
+            if (e != hipSuccess) return hip_fail(e, "collapse_bvh4_device");
+            s->b4_num = (size_t)n4;
+            s->b4_depth = d4;
+            SR_HIP(s->d_b4cam.reserve((size_t)n4 * sizeof(sr::Bvh4Node)));
+            SR_HIP(s->d_b4light.reserve((size_t)n4 * sizeof(sr::Bvh4Node)));
         }
     } else if (modes & (1u << SR_MODE_BVH)) {
         sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(15, s->dbg[SR_DBG_BVH_LEAF]) : 7,

@@ -128,6 +128,9 @@ size_t ray_sort_temp_bytes(unsigned int cap);
 hipError_t ray_sort(const void* queue, const unsigned int* d_count, unsigned int cap, const RootBox& root, unsigned int* keys, unsigned int* keys2,
                     unsigned int* idx, unsigned int* order_out, void* temp, size_t temp_bytes, hipStream_t stream);
 
+// the four-wide tree collapsed from a device-resident binary tree (same rule as the host's collapse_bvh4); d_wide: >= num_nodes entries
+hipError_t collapse_bvh4_device(const BvhNode* d_nodes, int num_nodes, Bvh4Node* d_wide, int* num_wide, int* depth, hipStream_t stream);
+
 // fp32 TriSlab records of n triangles (TriangleIndex order) computed on the device from the FP64 vertices (sr_lbvh.hip)
 hipError_t make_slabs_device(const double* d_v9, int n, const RootBox& root, TriSlab* d_out, hipStream_t stream);
 

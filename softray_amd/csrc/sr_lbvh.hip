@@ -226,6 +226,93 @@ __global__ void k_make_slabs(const double* __restrict__ v9, int n, double cx, do
     out[i] = ok ? t : zero;
 }
 
+// ---- the four-wide tree of the packet walks, collapsed on the device (same rule as sr_host.cpp collapse_bvh4: a node takes its two
+//      children and, while it has fewer than four, replaces the inner child with the largest box by that child's two children) ----
+// One launch per level of the wide tree: every item (binary node, wide-node slot) writes its wide node and appends its inner
+// children to the next level's list (slots handed out by an atomic counter: the numbering depends on the schedule, the tree does not).
+__global__ void k_collapse_level(const BvhNode* __restrict__ nodes, const int2* __restrict__ in, int n_in, int2* __restrict__ out,
+                                 int* __restrict__ counters /* [0] next free wide node, [1] items appended */, Bvh4Node* __restrict__ wide) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_in) return;
+    const int2 item = in[i];
+    Bvh4Child ch[4];
+    int k = 0;
+    const auto child_of = [](const BvhNode& n, int side) {
+        Bvh4Child c;
+        for (int a = 0; a < 3; ++a) { c.lo[a] = side ? n.lo1[a] : n.lo0[a]; c.hi[a] = side ? n.hi1[a] : n.hi0[a]; }
+        c.c = side ? n.c1 : n.c0;
+        c.n = side ? n.n1 : n.n0;
+        return c;
+    };
+    const auto area = [](const Bvh4Child& c) {
+        const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    };
+    {
+        const BvhNode r = nodes[item.x];
+        const Bvh4Child a = child_of(r, 0), b = child_of(r, 1);
+        if (a.n >= 0) ch[k++] = a;
+        if (b.n >= 0) ch[k++] = b;
+    }
+    while (k < 4) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (int j = 0; j < k; ++j)
+            if (ch[j].n == 0) { const float a = area(ch[j]); if (a > best_area) { best_area = a; best = j; } }
+        if (best < 0) break;
+        const BvhNode m = nodes[ch[best].c];
+        for (int j = k; j > best + 1; --j) ch[j] = ch[j - 1];
+        ch[best] = child_of(m, 0);
+        ch[best + 1] = child_of(m, 1);
+        ++k;
+    }
+    for (int j = 0; j < k; ++j) {
+        if (ch[j].n == 0) {
+            const int dst = atomicAdd(&counters[0], 1);
+            out[atomicAdd(&counters[1], 1)] = make_int2(ch[j].c, dst);
+            ch[j].c = dst;
+        }
+    }
+    for (int j = k; j < 4; ++j) {
+        for (int a = 0; a < 3; ++a) { ch[j].lo[a] = 1.0f; ch[j].hi[a] = -1.0f; }
+        ch[j].c = 0; ch[j].n = -1;
+    }
+    Bvh4Node w;
+    for (int j = 0; j < 4; ++j) w.ch[j] = ch[j];
+    wide[item.y] = w;
+}
+
+hipError_t collapse_bvh4_device(const BvhNode* d_nodes, int num_nodes, Bvh4Node* d_wide, int* num_wide, int* depth, hipStream_t stream) {
+    *num_wide = 0; *depth = 0;
+    if (num_nodes <= 0) return hipSuccess;
+    Tmp la, lb, ctr;
+    LB_HIP(la.alloc((size_t)num_nodes * sizeof(int2)));
+    LB_HIP(lb.alloc((size_t)num_nodes * sizeof(int2)));
+    LB_HIP(ctr.alloc(8));
+    const int2 root = make_int2(0, 0);
+    int init[2] = {1, 0};
+    LB_HIP(hipMemcpyAsync(la.p, &root, sizeof(root), hipMemcpyHostToDevice, stream));
+    LB_HIP(hipMemcpyAsync(ctr.p, init, 8, hipMemcpyHostToDevice, stream));
+    int n_in = 1, levels = 0;
+    int2* in = la.as<int2>();
+    int2* out = lb.as<int2>();
+    while (n_in > 0) {
+        ++levels;
+        if (levels > 256) return hipErrorUnknown;                 // (a tree deeper than that is refused by sr_build anyway)
+        hipLaunchKernelGGL(k_collapse_level, dim3((unsigned)((n_in + 255) / 256)), dim3(256), 0, stream, d_nodes, (const int2*)in, n_in, out, ctr.as<int>(), d_wide);
+        LB_HIP(hipGetLastError());
+        int c[2];
+        LB_HIP(hipMemcpyAsync(c, ctr.p, 8, hipMemcpyDeviceToHost, stream));
+        LB_HIP(hipStreamSynchronize(stream));
+        n_in = c[1];
+        *num_wide = c[0];
+        LB_HIP(hipMemsetAsync(ctr.as<int>() + 1, 0, 4, stream));
+        std::swap(in, out);
+    }
+    *depth = levels;
+    return hipSuccess;
+}
+
 hipError_t make_slabs_device(const double* d_v9, int n, const RootBox& root, TriSlab* d_out, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_make_slabs, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_v9, n, root.centre[0], root.centre[1], root.centre[2], d_out);

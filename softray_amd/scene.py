@@ -80,8 +80,10 @@ class GpuScene:
                 arr[i].p[j] = v
         _check(_lib.lib().sr_set_extra_geometry(self._h, arr, len(prims)))
 
-    def build(self, modes=(_lib.MODE_REF_TREE,), max_depth=0, max_per_leaf=0, on_device=False):
-        mask = _lib.BUILD_ON_DEVICE if on_device else 0
+    def build(self, modes=(_lib.MODE_REF_TREE,), max_depth=0, max_per_leaf=0, on_device=None):
+        """on_device: None = the library's default for the own BVH (device LBVH when the scene has a device), True = insist on the
+        device build, False = the host's binned-SAH builder."""
+        mask = 0 if on_device is None else (_lib.BUILD_ON_DEVICE if on_device else _lib.BUILD_ON_HOST)
         for m in modes:
             mask |= 1 << m
         _check(_lib.lib().sr_build(self._h, mask, max_depth, max_per_leaf))

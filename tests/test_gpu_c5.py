@@ -33,7 +33,7 @@ def c5_scene():
     bmin, bmax = np.array([-0.5] * 3), np.array([0.5] * 3)
     g = sa.GpuScene(0)
     g.set_triangles(v9, argb, bmin, bmax)
-    g.build((sa.MODE_BVH,))                                   # host SAH build (the default)
+    g.build((sa.MODE_BVH,), on_device=False)                  # host SAH build (the device LBVH is the default; see test_c5_device_built_bvh_same_pixels)
     depth, nodes, ntri, on_dev = g.bvh_stats()
     assert ntri == 10_000_000 and nodes > (1 << 20) and not on_dev          # node indices beyond 20 bits, record offsets beyond 23
     o = orc.Scene()

@@ -459,7 +459,7 @@ def test_packet_shaft_walk_against_private_walks():
     g = sa.GpuScene(0); o = orc.Scene()
     for s_ in (g, o):
         s_.set_triangles(v9, argb, bmin, bmax)
-    g.build((sa.MODE_BVH,)); assert o.build_tree() == 0
+    g.build((sa.MODE_BVH,), on_device=False); assert o.build_tree() == 0          # the host's binned-SAH tree (the other tests walk the default device LBVH)
     for kw in (dict(), dict(sub_pixel_res=2), dict(yaw_deg=10.0, pitch_deg=80.0), dict(start_row=5, end_row=70)):
         f = make_frame(117, 91, depth=1.5, shadows=True, **kw)
         want, _ = o.render(f, threads=NCPU)
@@ -502,7 +502,7 @@ def test_packet_primary_walk_against_private_walks():
     g = sa.GpuScene(0); o = orc.Scene()
     for s_ in (g, o):
         s_.set_triangles(v9, argb, bmin, bmax)
-    g.build((sa.MODE_BVH,)); assert o.build_tree() == 0
+    g.build((sa.MODE_BVH,), on_device=False); assert o.build_tree() == 0          # the host's binned-SAH tree (the other tests walk the default device LBVH)
     cases = [dict(), dict(sub_pixel_res=3), dict(sub_pixel_res=2, focal_blur=True), dict(depth=0.2), dict(yaw_deg=300.0, pitch_deg=40.0, roll_deg=25.0),
              dict(shadows=True), dict(start_row=9, end_row=40)]
     for kw in cases:
@@ -750,7 +750,8 @@ def test_device_built_bvh_gives_identical_pixels():
         v9, argb, bmin, bmax = unit_cube_scene(n)
         g = sa.GpuScene(0)
         g.set_triangles(v9, argb, bmin, bmax)
-        g.build((sa.MODE_BVH,))                       # host SAH build
+        g.build((sa.MODE_BVH,), on_device=False)      # host SAH build
+        assert g.bvh_stats()[3] == 0
         f = make_frame(res, depth=1.5, shadows=True)
         a, _ = g.render(as_sr(f, sa.MODE_BVH))
         rnd = orc.Random(5)
@@ -758,7 +759,8 @@ def test_device_built_bvh_gives_identical_pixels():
         starts = 3.0 * u[:, :3] - 1.5
         dirs = (u[:, 3:] - 0.5) - starts
         ta = g.trace(sa.MODE_BVH, starts, dirs)
-        g.build((sa.MODE_BVH,), on_device=True)       # device LBVH build replaces it
+        g.build((sa.MODE_BVH,))                       # the default: the device LBVH build replaces it
+        assert g.bvh_stats()[3] == (1 if n > 64 else 0)
         b, _ = g.render(as_sr(f, sa.MODE_BVH))
         assert np.array_equal(a, b), n
         tb = g.trace(sa.MODE_BVH, starts, dirs)
