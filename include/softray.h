@@ -315,7 +315,7 @@ enum {
     SR_DBG_ROUND_CAP1     = 2,   /* ... of round 2 (default 64, <= 1024): tiny lists force round 2 and the exact fallback      */
     SR_DBG_SPLIT          = 3,   /* concurrent part-frame pipelines (default 2, <= 4)                                          */
     SR_DBG_FB_RAY_CAP     = 4,   /* capacity of the fallback ray list                                                          */
-    SR_DBG_BVH_LEAF       = 5,   /* triangles per leaf of the host SAH build (default 7, 1..15); read by the next sr_build      */
+    SR_DBG_BVH_LEAF       = 5,   /* triangles per leaf of the own BVH, host and device build (default 4, 1..15); read by the next sr_build */
     SR_DBG_KERNEL_SWITCH  = 6,   /* FrameConst.debug: kernel-internal experiment switch (0 = production)                       */
     SR_DBG_KERNEL_TIMING  = 7,   /* > 0: record a HIP event pair around every launch (sr_kernel_times); default off           */
     SR_DBG_EXACT_SHADOW_TESTS = 8, /* > 0: k_shadow_test decides every (sample, triangle) pair with the FP64 arithmetic (no

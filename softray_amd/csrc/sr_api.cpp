@@ -929,7 +929,8 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         SR_HIP(s->d_bslab.reserve(n * sizeof(sr::TriSlab)));
         int nn = 0, depth = 0;
         hipError_t e = sr::build_bvh_device((const double*)d_v9.p, (int)n, s->root, (const sr::Rec128*)s->d_tris.p, (const sr::TriSlab*)d_slab.p,
-                                            (sr::BvhNode*)s->d_bnodes.p, (sr::Rec128*)s->d_btris.p, (sr::TriSlab*)s->d_bslab.p, &nn, &depth, nullptr);
+                                            (sr::BvhNode*)s->d_bnodes.p, (sr::Rec128*)s->d_btris.p, (sr::TriSlab*)s->d_bslab.p, &nn, &depth, nullptr,
+                                            s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(15, s->dbg[SR_DBG_BVH_LEAF]) : 0);
         d_slab.release();
         if (e != hipSuccess) return hip_fail(e, "build_bvh_device");
         if (depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
@@ -953,7 +954,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
             SR_HIP(s->d_b4light.reserve((size_t)n4 * sizeof(sr::Bvh4Node)));
         }
     } else if (modes & (1u << SR_MODE_BVH)) {
-        sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(15, s->dbg[SR_DBG_BVH_LEAF]) : 7,
+        sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(15, s->dbg[SR_DBG_BVH_LEAF]) : 4,
                       s->dbg[SR_DBG_BUILD_THREADS] > 0 ? (int)std::min<int64_t>(64, s->dbg[SR_DBG_BUILD_THREADS]) : 0);
         if (s->bvh.depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
         s->bvh_on_device = false;

@@ -121,7 +121,7 @@ size_t pipeline_round_state_bytes();
 hipError_t gather_records_device(int n, const unsigned int* d_order, const Rec128* d_tris, Rec128* d_btris, const TriSlab* d_slab_in,
                                  TriSlab* d_bslab, hipStream_t stream);
 hipError_t build_bvh_device(const double* d_v9, int n, const RootBox& root, const Rec128* d_tris, const TriSlab* d_slab_in,
-                            BvhNode* d_nodes, Rec128* d_btris, TriSlab* d_bslab, int* num_nodes, int* depth, hipStream_t stream);
+                            BvhNode* d_nodes, Rec128* d_btris, TriSlab* d_bslab, int* num_nodes, int* depth, hipStream_t stream, int leaf_max = 0);
 
 // order of a bounce level's ray queue by (origin cell, direction octant) (sr_raysort.hip): order_out = permutation of [0, cap)
 size_t ray_sort_temp_bytes(unsigned int cap);

@@ -268,7 +268,7 @@ struct BvhBuilder {
     Bvh& out;
     const RootBox& root;
     double pad;
-    int kLeafMax = 7;                // triangles per leaf (measured on the packet walks: 2: 22.7 ms, 4: 20.8, 7: 19.5, 10: 19.9, 15: 20.0) (sr_debug_set(SR_DBG_BVH_LEAF) = 1..7 overrides: experiment hook)
+    int kLeafMax = 4;                // triangles per leaf; set by build_bvh.  Round 3, four-wide packet walks with per-frame ordered children: 2: 11.9 ms, 3: 11.6, 4: 11.5, 5: 11.6, 7: 11.8, 10: 12.3, 14: 12.9 (round 2's binary packet walks preferred 7: 2: 22.7, 4: 20.8, 7: 19.5, 10: 19.9) (sr_debug_set(SR_DBG_BVH_LEAF) = 1..15 overrides)
     int threads = 1;
 
     struct Task { int b, e, depth; int32_t parent; int side; Bounds bd; int src; };

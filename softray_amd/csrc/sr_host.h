@@ -55,7 +55,7 @@ struct Bvh {
     bool built = false;
 };
 // threads: 0 = the host's cores (at most 16); the tree does not depend on it
-void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int leaf_max = 7, int threads = 0);
+void build_bvh(const std::vector<double>& v9, const RootBox& root, Bvh& out, int leaf_max = 4, int threads = 0);
 // The BVH2 collapsed to <= 4 children per node (sr_types.h Bvh4Node): a node takes its two children and, while it has fewer
 // than four, replaces the inner child with the largest box by that child's two children.  Boxes, leaves and the leaf order are
 // the BVH2's, so both trees describe the same hierarchy of the same records.  Returns the depth (root = 1).

@@ -94,7 +94,7 @@ def test_wide_tree_is_the_binary_tree_collapsed():
         depth2, nodes2, tris, _ = s.bvh_stats()
         depth4, nodes4, slots, leaves, leaf_tris = s.wide_tree_stats()
         assert leaf_tris == tris == n
-        leaves2 = nodes2 + 1 if n > 7 else 1            # (a scene that fits one leaf: a root record with one leaf child)
+        leaves2 = nodes2 + 1 if n > 4 else 1            # (a scene that fits one leaf: a root record with one leaf child)
         assert leaves == leaves2, (n, leaves, leaves2)
         assert slots == leaves + nodes4 - 1             # every node but the root sits in exactly one slot
         assert nodes4 <= nodes2 and depth4 <= depth2 and 3 * depth4 >= depth2 - 2
