@@ -99,7 +99,7 @@ def test_wide_tree_is_the_binary_tree_collapsed():
         assert slots == leaves + nodes4 - 1             # every node but the root sits in exactly one slot
         assert nodes4 <= nodes2 and depth4 <= depth2 and 3 * depth4 >= depth2 - 2
         if n >= 300:
-            assert slots / nodes4 > 3.0                  # the greedy collapse fills the nodes
+            assert slots / nodes4 > 2.8                  # the greedy collapse fills the nodes (4 wherever a node has enough descendants)
 
 
 def test_no_cpu_fallback():
