@@ -13,7 +13,7 @@ os.makedirs(dst, exist_ok=True)
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(dst, "bench_under_rocprof.json"))
 
-FAMILIES = ("k_primary", "k_cam_cones", "k_shaft_pkt", "k_shaft", "k_shadow_cls", "k_shadow_test", "k_shadow_wave", "k_shadow_rays",
+FAMILIES = ("k_primary", "k_cam_cones", "k_order_nodes", "k_ray_keys", "k_shaft_pkt", "k_shaft", "k_shadow_cls", "k_shadow_test", "k_shadow_wave", "k_shadow_rays",
             "k_fb_expand", "k_fb_resolve", "k_bounce", "k_fold", "k_resolve", "k_post_process", "k_anti_alias")
 STATS_ARG = {"k_primary": 2, "k_shaft_pkt": 0, "k_shaft": 0, "k_shadow_cls": 1, "k_shadow_test": 1, "k_shadow_rays": 1, "k_shadow_wave": 1, "k_bounce": 1}
 
