@@ -70,6 +70,10 @@ struct sr_scene {
     double bmin[3] = {0, 0, 0}, bmax[3] = {0, 0, 0};
     double vmin[3] = {0, 0, 0}, vmax[3] = {0, 0, 0};   // bounds of the vertices themselves (the caller's box need not be tight, nor, in brute-force mode, contain them)
     bool have_model = false;
+    size_t ntris = 0;                      // triangles of the model (a part of a multi-device scene keeps the count, not the arrays)
+    // (part of a multi-device scene) the scene whose HOST arrays -- vertices, records, reference tree, SAH nodes and order -- this
+    // part uploads from: the model lives once on the host however many devices render it
+    const sr_scene* host_src = nullptr;
     std::vector<sr::Rec128> tri_recs;      // geometry_simple, Renderer.cs:1452-1469
     std::vector<sr::Rec128> extra_recs;    // ExtraGeometryToRaytrace
     sr::RootBox root{};
@@ -86,6 +90,7 @@ struct sr_scene {
     size_t b4_num = 0;
     int    b4_depth = 0;
     bool   b4cam_valid = false, b4light_valid = false;
+    int    b4cam_known = 0, b4light_known = 0;   // axes on which the ordered copy holds (near, far) planes (sr_device.h)
     double b4_light[3] = {0, 0, 0};      // light position the order of d_b4light was made for
     // the per-origin / per-light records above are written on whatever stream the frame that needs them runs on: `pre_ready` is
     // recorded after every rewrite and waited for by every frame (another stream may use them next), `pre_used` is recorded at the
@@ -156,6 +161,17 @@ int use_device(sr_scene* s) {
     return SR_OK;
 }
 
+// axes on which `p` lies outside the root box's slab (by more than the shadow probe offset and the boxes' padding): known = those axes,
+// beyond = those of them on which p lies ABOVE the box
+void point_outside_axes(const sr::RootBox& root, const double p[3], int& known, int& beyond) {
+    known = beyond = 0;
+    for (int a = 0; a < 3; ++a) {
+        const double margin = 0.01 + 1e-3 * (root.max[a] - root.min[a]);
+        if (p[a] > root.max[a] + margin) { known |= 1 << a; beyond |= 1 << a; }
+        else if (p[a] < root.min[a] - margin) known |= 1 << a;
+    }
+}
+
 // the four-wide tree of the packet walks = the binary tree collapsed on the host (sr_host.cpp collapse_bvh4)
 int upload_wide_tree(sr_scene* s, const sr::BvhNode* nodes, size_t num_nodes) {
     std::vector<sr::Bvh4Node> wide;
@@ -170,21 +186,22 @@ int upload_wide_tree(sr_scene* s, const sr::BvhNode* nodes, size_t num_nodes) {
 }
 
 int sync_geometry(sr_scene* s, uint32_t need_mode) {
-    if (s->tris_dirty) { SR_HIP(s->d_tris.upload(s->tri_recs)); SR_HIP(s->d_v9.upload(s->v9)); s->tris_dirty = false; s->cam_valid = false; }
+    const sr_scene* h = s->host_src ? s->host_src : s;              // where the host arrays are
+    if (s->tris_dirty) { SR_HIP(s->d_tris.upload(h->tri_recs)); SR_HIP(s->d_v9.upload(h->v9)); s->tris_dirty = false; s->cam_valid = false; }
     if (s->extra_dirty) { SR_HIP(s->d_extra.upload(s->extra_recs)); s->extra_dirty = false; }
     if (need_mode == SR_MODE_REF_TREE && s->ref_dirty) {
-        SR_HIP(s->d_rnodes.upload(s->ref.nodes));
-        SR_HIP(s->d_rboxes.upload(s->ref.leaf_boxes));
-        SR_HIP(s->d_rleaf.upload(s->ref.leaf_tris));
+        SR_HIP(s->d_rnodes.upload(h->ref.nodes));
+        SR_HIP(s->d_rboxes.upload(h->ref.leaf_boxes));
+        SR_HIP(s->d_rleaf.upload(h->ref.leaf_tris));
         s->ref_dirty = false;
     }
     if (need_mode == SR_MODE_BVH && s->bvh_dirty && !s->bvh_on_device) {
-        SR_HIP(s->d_bnodes.upload(s->bvh.nodes));
+        SR_HIP(s->d_bnodes.upload(h->bvh.nodes));
         // the leaf-order copies of the FP64 records and the fp32 shaft records are made on the device from the TriangleIndex-order
         // arrays that are there already: only the order (4 B per triangle) travels
-        const size_t n = s->bvh.order.size();
+        const size_t n = h->bvh.order.size();
         DBuf d_order, d_slab;
-        SR_HIP(d_order.upload(s->bvh.order));
+        SR_HIP(d_order.upload(h->bvh.order));
         SR_HIP(d_slab.reserve(n * sizeof(sr::TriSlab)));
         SR_HIP(sr::make_slabs_device((const double*)s->d_v9.p, (int)n, s->root, (sr::TriSlab*)d_slab.p, nullptr));
         SR_HIP(s->d_btris.reserve(n * sizeof(sr::Rec128)));
@@ -194,10 +211,10 @@ int sync_geometry(sr_scene* s, uint32_t need_mode) {
         SR_HIP(hipDeviceSynchronize());
         d_order.release();
         d_slab.release();
-        s->bvh_num_nodes = s->bvh.nodes.size();
+        s->bvh_num_nodes = h->bvh.nodes.size();
         s->bvh_dirty = false;
         s->cam_valid = false;
-        int rc = upload_wide_tree(s, s->bvh.nodes.data(), s->bvh.nodes.size());
+        int rc = upload_wide_tree(s, h->bvh.nodes.data(), h->bvh.nodes.size());
         if (rc) return rc;
     }
     return SR_OK;
@@ -205,7 +222,7 @@ int sync_geometry(sr_scene* s, uint32_t need_mode) {
 
 sr::DevScene dev_scene(const sr_scene* s) {
     sr::DevScene d{};
-    d.tris = (const sr::Rec128*)s->d_tris.p; d.ntris = (int32_t)s->tri_recs.size();
+    d.tris = (const sr::Rec128*)s->d_tris.p; d.ntris = (int32_t)s->ntris;
     d.extra = (const sr::Rec128*)s->d_extra.p; d.nextra = (int32_t)s->extra_recs.size();
     d.rnodes = (const sr::RefNode*)s->d_rnodes.p; d.rboxes = (const sr::LeafBox*)s->d_rboxes.p; d.rleaf = (const int32_t*)s->d_rleaf.p;
     d.rdepth = s->ref.tree_depth;
@@ -217,6 +234,7 @@ sr::DevScene dev_scene(const sr_scene* s) {
     d.b4cam = (s->b4cam_valid && s->cam_valid) ? (const sr::Bvh4Node*)s->d_b4cam.p : nullptr;
     d.b4light = s->b4light_valid ? (const sr::Bvh4Node*)s->d_b4light.p : nullptr;
     d.b4depth = s->b4_depth;
+    d.b4cam_known = s->b4cam_known; d.b4light_known = s->b4light_known;
     d.bnode_bits = 1;
     while ((1ull << d.bnode_bits) < s->bvh_num_nodes + 1 && d.bnode_bits < 26) d.bnode_bits++;
     d.root = s->root;
@@ -225,7 +243,7 @@ sr::DevScene dev_scene(const sr_scene* s) {
 }
 
 int check_mode(const sr_scene* s, int mode) {
-    if (!s->have_model || s->tri_recs.empty()) return fail(SR_ERR_NO_MODEL, "no model: Render() returns without drawing (Renderer.cs:736-739)");
+    if (!s->have_model || s->ntris == 0) return fail(SR_ERR_NO_MODEL, "no model: Render() returns without drawing (Renderer.cs:736-739)");
     if (mode == SR_MODE_REF_TREE && !s->ref.built) return fail(SR_ERR_NOT_BUILT, "SR_MODE_REF_TREE needs sr_build(1 << SR_MODE_REF_TREE)");
     if (mode == SR_MODE_REF_TREE && s->ref.tree_depth > 120) return fail(SR_ERR_UNSUPPORTED, "reference tree deeper than 120 levels does not fit the LDS traversal stacks");
     if (mode == SR_MODE_BVH && !s->bvh.built) return fail(SR_ERR_NOT_BUILT, "SR_MODE_BVH needs sr_build(1 << SR_MODE_BVH)");
@@ -452,7 +470,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         return hipStreamWaitEvent(stream, s->pre_used, 0);
     };
     if (f->trace_mode == SR_MODE_BVH && s->dbg[SR_DBG_PER_LANE_PRIMARY] <= 0 && !((f->flags & SR_F_FOCAL_BLUR) && f->sub_pixel_res > 1)) {
-        const size_t nt = s->tri_recs.size();
+        const size_t nt = s->ntris;
         const bool same_origin = s->cam_origin[0] == fc.start_world[0] && s->cam_origin[1] == fc.start_world[1] && s->cam_origin[2] == fc.start_world[2];
         if (!s->cam_valid || !same_origin) {
             SR_HIP(s->d_bcam.reserve(nt * sizeof(sr::CamCone)));
@@ -467,7 +485,12 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         if (wide && !s->b4cam_valid) {                                // the four-wide nodes, children front to back for this origin
             SR_HIP(before_rewrite());
             rewrote = true;
-            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4cam.p, (int)s->b4_num, s->root, fc.start_world, false, stream));
+            int known, swap;                                      // (a camera ABOVE the box on an axis looks towards smaller coordinates: hi first)
+            point_outside_axes(s->root, fc.start_world, known, swap);
+            // the camera-ordered copy holds (near, far) planes only when that is true on ALL axes (one extra instantiation of k_primary, not seven)
+            if (known != 7 || s->dbg[SR_DBG_KERNEL_SWITCH] == 61) known = swap = 0;
+            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4cam.p, (int)s->b4_num, s->root, fc.start_world, false, swap, stream));
+            s->b4cam_known = known;
             s->b4cam_valid = true;
         }
     }
@@ -477,7 +500,13 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             SR_HIP(before_rewrite());
             rewrote = true;
             s->b4light_valid = false;
-            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4light.p, (int)s->b4_num, s->root, fc.light_pos_model, true, stream));
+            int known, swap;                                      // (swap = the axes on which the light lies ABOVE the box)
+            point_outside_axes(s->root, fc.light_pos_model, known, swap);
+            if (s->dbg[SR_DBG_KERNEL_SWITCH] == 61) known = swap = 0;
+            // the shafts run from the surface points TOWARDS the light: on an axis where the light lies above the box they travel towards
+            // larger coordinates (lo first: no swap), where it lies below, towards smaller ones
+            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4light.p, (int)s->b4_num, s->root, fc.light_pos_model, true, known & ~swap & 7, stream));
+            s->b4light_known = known;
             for (int i = 0; i < 3; ++i) s->b4_light[i] = fc.light_pos_model[i];
             s->b4light_valid = true;
         }
@@ -711,16 +740,32 @@ hipError_t copy_runs(const std::vector<StripRun>& runs, int n, int width, const 
 // frames that cannot be split (one global fill order) are rendered whole by the first part
 bool multi_splittable(const sr_frame* f) { return !((f->flags & SR_F_STATIC_SHADOWS) && (f->flags & SR_F_SHADOWS)) && f->strip_count <= 0; }
 
-void clone_host_model(sr_scene* d, const sr_scene* src) {
-    d->v9 = src->v9; d->argb = src->argb;
+// a part of a multi-device scene takes the first part's model by reference: counts, box and flags here, the arrays stay with `src`
+// (sync_geometry uploads from them); nothing of the size of the model is copied on the host
+void share_host_model(sr_scene* d, const sr_scene* src) {
+    d->host_src = src;
+    d->v9.clear(); d->argb.clear(); d->tri_recs.clear();
+    d->ntris = src->ntris;
     for (int a = 0; a < 3; ++a) { d->bmin[a] = src->bmin[a]; d->bmax[a] = src->bmax[a]; d->vmin[a] = src->vmin[a]; d->vmax[a] = src->vmax[a]; }
     d->have_model = src->have_model;
-    d->tri_recs = src->tri_recs;
     d->root = src->root;
     d->shadow_cache_empty = true;
     d->ref = sr::RefTree(); d->bvh = sr::Bvh(); d->bvh_on_device = false;
     d->tris_dirty = d->ref_dirty = d->bvh_dirty = true;
     d->cam_valid = false;
+}
+// ... and its host-built structures: the numbers a part needs (built / depth / counts), not the node arrays
+void share_ref_tree(sr_scene* d, const sr_scene* src) {
+    d->ref = sr::RefTree();
+    d->ref.built = src->ref.built; d->ref.tree_depth = src->ref.tree_depth; d->ref.num_nodes = src->ref.num_nodes;
+    d->ref.num_leaf_nodes = src->ref.num_leaf_nodes; d->ref.max_stack = src->ref.max_stack;
+    d->ref_dirty = true;
+}
+void share_host_bvh(sr_scene* d, const sr_scene* src) {
+    d->bvh = sr::Bvh();
+    d->bvh.built = src->bvh.built; d->bvh.depth = src->bvh.depth;
+    d->bvh_on_device = false;
+    d->bvh_dirty = true;
 }
 
 }  // namespace
@@ -816,7 +861,7 @@ void sr_destroy(sr_scene* s) {
 int sr_set_triangles(sr_scene* s, const double* v9, const uint32_t* argb, int64_t n, const double box_min[3], const double box_max[3]) {
     if (s && !s->parts.empty()) {                                  // host work once, the records are replicated
         int rc = sr_set_triangles(s->parts[0], v9, argb, n, box_min, box_max);
-        for (size_t i = 1; i < s->parts.size() && !rc; ++i) clone_host_model(s->parts[i], s->parts[0]);
+        for (size_t i = 1; i < s->parts.size() && !rc; ++i) share_host_model(s->parts[i], s->parts[0]);
         return rc;
     }
     if (!s || n < 0 || (n > 0 && (!v9 || !argb)) || !box_min || !box_max) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_set_triangles");
@@ -829,6 +874,7 @@ int sr_set_triangles(sr_scene* s, const double* v9, const uint32_t* argb, int64_
     for (int a = 0; a < 3; ++a) { s->vmin[a] = box_min[a]; s->vmax[a] = box_max[a]; }
     for (int64_t i = 0; i < 3 * n; ++i)
         for (int a = 0; a < 3; ++a) { s->vmin[a] = std::min(s->vmin[a], v9[3 * i + a]); s->vmax[a] = std::max(s->vmax[a], v9[3 * i + a]); }
+    s->ntris = (size_t)n;
     s->tri_recs.resize((size_t)n);
     for (int64_t i = 0; i < n; ++i) {
         const double* p = &s->v9[9 * i];
@@ -885,13 +931,13 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         for (size_t i = 1; i < s->parts.size() && !rc; ++i) {
             sr_scene* q = s->parts[i];
             if (!(modes & SR_BUILD_ON_HOST) && (modes & (1u << SR_MODE_BVH)) && s->parts[0]->bvh_on_device) {
-                q->ref = s->parts[0]->ref; q->ref_dirty = true;
+                share_ref_tree(q, s->parts[0]);
                 rc = sr_build(q, modes & ~(1u << SR_MODE_REF_TREE), max_depth, max_per_leaf);
                 if (!rc && (modes & (1u << SR_MODE_REF_TREE)) && (rc = use_device(q)) == SR_OK) rc = sync_geometry(q, SR_MODE_REF_TREE);
                 continue;
             }
-            if (modes & (1u << SR_MODE_REF_TREE)) { q->ref = s->parts[0]->ref; q->ref_dirty = true; }
-            if (modes & (1u << SR_MODE_BVH)) { q->bvh = s->parts[0]->bvh; q->bvh_on_device = false; q->bvh_dirty = true; }
+            if (modes & (1u << SR_MODE_REF_TREE)) share_ref_tree(q, s->parts[0]);
+            if (modes & (1u << SR_MODE_BVH)) share_host_bvh(q, s->parts[0]);
             if ((rc = use_device(q))) break;
             if (modes & (1u << SR_MODE_REF_TREE)) if ((rc = sync_geometry(q, SR_MODE_REF_TREE))) break;
             if (modes & (1u << SR_MODE_BVH)) if ((rc = sync_geometry(q, SR_MODE_BVH))) break;
@@ -902,7 +948,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
     if (!s) return fail(SR_ERR_INVALID_ARG, "scene is NULL");
     if (!s->have_model) return fail(SR_ERR_NO_MODEL, "sr_build before sr_set_triangles");
     // leaves are packed as (first record | count << 27) and traversal stack words as (node | bound << bits): 2^28 records / 2^26 nodes
-    if ((modes & (1u << SR_MODE_BVH)) && s->argb.size() >= (1u << 26))
+    if ((modes & (1u << SR_MODE_BVH)) && s->ntris >= (1u << 26))
         return fail(SR_ERR_UNSUPPORTED, "the library's BVH holds at most 2^26 - 1 triangles");
     if (modes & (1u << SR_MODE_REF_TREE)) {
         int md = max_depth > 0 ? max_depth : 15, mg = max_per_leaf > 0 ? max_per_leaf : 25;   // SpatialSubdivision.cs:269-270
@@ -913,13 +959,13 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
     // the own BVH is built where the triangles are: on the device (LBVH, sr_lbvh.hip), unless the scene has none, is tiny, or the
     // caller asks for the host's binned-SAH builder (SR_BUILD_ON_HOST)
     if ((modes & SR_BUILD_ON_DEVICE) && s->device < 0) return fail(SR_ERR_NO_DEVICE, "SR_BUILD_ON_DEVICE needs a HIP device");
-    const bool on_device = s->device >= 0 && !(modes & SR_BUILD_ON_HOST) && s->argb.size() > 64;
+    const bool on_device = s->device >= 0 && !(modes & SR_BUILD_ON_HOST) && s->ntris > 64;
     if ((modes & (1u << SR_MODE_BVH)) && on_device) {
         // ---- LBVH built by the GPU (sr_lbvh.hip) ----
         int rc = use_device(s);
         if (rc) return rc;
         if ((rc = sync_geometry(s, SR_MODE_BRUTE))) return rc;            // d_tris
-        const size_t n = s->argb.size();
+        const size_t n = s->ntris;
         DBuf d_slab;
         DBuf& d_v9 = s->d_v9;                                             // uploaded by sync_geometry with the records
         SR_HIP(d_slab.reserve(n * sizeof(sr::TriSlab)));
@@ -982,7 +1028,7 @@ int sr_bvh_stats(const sr_scene* s, int64_t out[4]) {
     if (s && !s->parts.empty()) s = s->parts[0];
     if (!s || !out) return fail(SR_ERR_INVALID_ARG, "bad argument");
     if (!s->bvh.built) return fail(SR_ERR_NOT_BUILT, "BVH not built");
-    out[0] = s->bvh.depth; out[1] = (int64_t)(s->bvh_on_device ? s->bvh_num_nodes : s->bvh.nodes.size()); out[2] = (int64_t)s->tri_recs.size(); out[3] = s->bvh_on_device ? 1 : 0;
+    out[0] = s->bvh.depth; out[1] = (int64_t)(s->bvh_on_device ? s->bvh_num_nodes : s->bvh.nodes.size()); out[2] = (int64_t)s->ntris; out[3] = s->bvh_on_device ? 1 : 0;
     return SR_OK;
 }
 
@@ -1225,7 +1271,7 @@ int sr_trace_rays(sr_scene* s, int32_t target, int64_t n, const double* starts, 
     int mode = target & 0xff;
     if (!s->have_model) return fail(SR_ERR_NO_MODEL, "no model");
     int rc;
-    if (s->tri_recs.empty() && mode == SR_MODE_BRUTE) { /* empty model is fine for brute force */ }
+    if (s->ntris == 0 && mode == SR_MODE_BRUTE) { /* empty model is fine for brute force */ }
     else if ((rc = check_mode(s, mode))) return rc;
     if ((rc = use_device(s))) return rc;
     if ((rc = sync_geometry(s, (uint32_t)mode))) return rc;
@@ -1284,7 +1330,7 @@ int sr_load_3ds(sr_scene* s, const uint8_t* data, size_t len) {
     if (!err.empty()) return fail(SR_ERR_FORMAT, err);
     return sr_set_triangles(s, m.v9.data(), m.argb.data(), (int64_t)m.argb.size(), m.bmin, m.bmax);
 }
-int64_t sr_num_triangles(const sr_scene* s) { if (s && !s->parts.empty()) s = s->parts[0]; return s ? (int64_t)s->argb.size() : 0; }
+int64_t sr_num_triangles(const sr_scene* s) { if (s && !s->parts.empty()) s = s->parts[0]; return s ? (int64_t)s->ntris : 0; }
 int sr_get_triangles(const sr_scene* s, double* v9, uint32_t* argb, double box_min[3], double box_max[3]) {
     if (s && !s->parts.empty()) s = s->parts[0];
     if (!s || !s->have_model) return fail(SR_ERR_NO_MODEL, "no model");

@@ -32,6 +32,9 @@ struct DevScene {
     const Bvh4Node* b4cam;
     const Bvh4Node* b4light;
     int32_t        b4depth;
+    // axes (bit a) on which the ordered copy stores (near, far) instead of (lo, hi): the camera origin / the light lies outside the
+    // root box's slab on that axis, so every ray of the frame has the same sign there (child_slabs<KNOWN>, sr_trace.h)
+    int32_t        b4cam_known, b4light_known;
     RootBox        root;
     uint8_t*       shadow_cache; // static soft-shadow cache, 128^3 bytes, 0 = empty cell (SR_F_STATIC_SHADOWS frames)
 };
@@ -108,7 +111,8 @@ struct PipelineLaunch {
 hipError_t launch_pipeline(const PipelineLaunch& L);
 // per-frame pre-pass: a copy of the four-wide nodes with every node's children sorted by the distance of their box centres from
 // `point` (model space), nearest first (camera origin) or farthest first (light: nearest to the surface points first)
-hipError_t launch_order_nodes(const Bvh4Node* in, Bvh4Node* out, int num_nodes, const RootBox& root, const double point[3], bool far_first, hipStream_t stream);
+// swap_mask (bit a): exchange lo and hi on axis a in the copy (the rays of the frame travel towards smaller coordinates there)
+hipError_t launch_order_nodes(const Bvh4Node* in, Bvh4Node* out, int num_nodes, const RootBox& root, const double point[3], bool far_first, int swap_mask, hipStream_t stream);
 // per-frame pre-pass: camera-cone records of every BVH triangle for the ray origin `origin` (model space)
 hipError_t launch_cam_cones(const DevScene& sc, int ntris, const double origin[3], CamCone* out, hipStream_t stream);
 size_t pipeline_hit_record_bytes();

@@ -76,8 +76,9 @@ static int xcd_tile_grid(int width, int row_count) {
 // SUB = false: one ray per pixel (rayTraceSubPixelRes == 1), compiled without the sub-pixel / focal-blur state
 // PKT (own BVH, all rays of the frame share one origin): the wave walks the tree once (bvh_packet_nearest, sr_trace.h) and
 // consults the frame's camera-cone records before the FP64 triangle test
-// PKT = 2: the packet walk on the four-wide tree's camera-ordered copy (bvh4_packet_nearest), the default; PKT = 1: on the binary
-// tree with a per-step vote (cross-check)
+// PKT = 2: the packet walk on the four-wide tree's camera-ordered copy (bvh4_packet_nearest), the default; PKT = 3: the same with the
+// camera outside the root box's slab on all three axes (the copy holds (near, far) planes: no min / max per axis); PKT = 1: on the
+// binary tree with a per-step vote (cross-check)
 template <int MODE, bool EXTRA, bool STATS, bool SUB, int PKT>
 __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
                                                  int row_count, uint32_t* __restrict__ samples, HitRec* __restrict__ hits,
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
         bool ok = false;
         if (PKT) {
             if (live) prim.rays++;
-            ok = root_intersect_pkt<EXTRA, true, PKT == 2>(sc, sc.extra, wnode, live, ss, dw, h, prim);     // all 64 lanes take part
+            ok = root_intersect_pkt<EXTRA, true, PKT == 3 ? 2 : (PKT == 2 ? 1 : 0)>(sc, sc.extra, wnode, live, ss, dw, h, prim);     // all 64 lanes take part
         } else if (live) {
             prim.rays++;
             ok = root_intersect<MODE, false, EXTRA>(sc, sc.tris, sc.extra, st, ss, dw, h, prim);
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc
 // the candidate lists may differ in order and in which candidates a truncated list holds, which no later stage depends on.
 // LDS per wave: [levels] node words + [levels][64] 16-bit bounds, levels = 3 * b4depth + 2.
 // --------------------------------------------------------------------------------------------------
-template <bool STATS, int WAVES>
+template <bool STATS, int WAVES, int KNOWN>
 __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
                                                     const unsigned int* __restrict__ hit_count, int cap, int levels, int tile_n2, int tile_rows,
                                                     unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
@@ -922,7 +923,10 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameCon
     const float ix = slab_inv(dx), iy = slab_inv(dy), iz = slab_inv(dz);
     const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
     const f2 OI01 = {-ex * ix, -ey * iy}, OI20 = {-ez * iz, -ex * ix}, OI12 = {-ey * iy, -ez * iz};
-    const f2 RI01 = {-ix, -iy}, RI20 = {-iz, ix}, RI12 = {iy, iz};
+    // the box grows by r on every side: its near plane moves EARLIER, its far plane later.  Where the copy holds (lo, hi) that is
+    // -r i for lo and +r i for hi whatever the sign of i (the min / max sort it out); where it holds (near, far) it is -r |i| / +r |i|
+    const float rx = (KNOWN & 1) ? fabsf(ix) : ix, ry = (KNOWN & 2) ? fabsf(iy) : iy, rz = (KNOWN & 4) ? fabsf(iz) : iz;
+    const f2 RI01 = {-rx, -ry}, RI20 = {-rz, rx}, RI12 = {ry, rz};
     const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
     const ShaftRay sr = make_shaft_ray(sc, fc, E, lpos);
     int32_t* out = cand + (size_t)slot_i * cap;
@@ -951,10 +955,10 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameCon
         const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
         const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
         float a0, b0, a1, b1, a2, b2, a3, b3;                          // child u-intervals [a, b] of this lane's shaft
-        child_slabs(n.ch[0], I01, I20, I12, B0, B1, B2, a0, b0);
-        child_slabs(n.ch[1], I01, I20, I12, B0, B1, B2, a1, b1);
-        child_slabs(n.ch[2], I01, I20, I12, B0, B1, B2, a2, b2);
-        child_slabs(n.ch[3], I01, I20, I12, B0, B1, B2, a3, b3);
+        child_slabs<KNOWN>(n.ch[0], I01, I20, I12, B0, B1, B2, a0, b0);
+        child_slabs<KNOWN>(n.ch[1], I01, I20, I12, B0, B1, B2, a1, b1);
+        child_slabs<KNOWN>(n.ch[2], I01, I20, I12, B0, B1, B2, a2, b2);
+        child_slabs<KNOWN>(n.ch[3], I01, I20, I12, B0, B1, B2, a3, b3);
         b0 = fminf(b0, nu); b1 = fminf(b1, nu); b2 = fminf(b2, nu); b3 = fminf(b3, nu);
         const bool h0 = !done && n.ch[0].n >= 0 && fmaxf(a0, umin) <= b0, h1 = !done && n.ch[1].n >= 0 && fmaxf(a1, umin) <= b1;
         const bool h2 = !done && n.ch[2].n >= 0 && fmaxf(a2, umin) <= b2, h3 = !done && n.ch[3].n >= 0 && fmaxf(a3, umin) <= b3;
@@ -2365,7 +2369,8 @@ __global__ __launch_bounds__(256) void k_cam_cones(const Rec128* __restrict__ bt
 // Links are untouched (a child keeps its node index), only the slots move; the sort is stable, so equal keys keep build order.
 // 128 B read + 128 B written per node: 17 MB at 1 M triangles; re-run only when the point or the tree changed.
 // --------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_order_nodes(const Bvh4Node* __restrict__ in, Bvh4Node* __restrict__ out, int n, float px, float py, float pz, int far_first) {
+__global__ __launch_bounds__(256) void k_order_nodes(const Bvh4Node* __restrict__ in, Bvh4Node* __restrict__ out, int n, float px, float py, float pz, int far_first,
+                                                     int swap_mask) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     Bvh4Node nd = in[i];
@@ -2388,13 +2393,19 @@ __global__ __launch_bounds__(256) void k_order_nodes(const Bvh4Node* __restrict_
             }
         }
     }
+    // (near, far) instead of (lo, hi) on the axes where every ray of the frame travels towards smaller coordinates
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            if ((swap_mask >> a) & 1) { const float t = nd.ch[k].lo[a]; nd.ch[k].lo[a] = nd.ch[k].hi[a]; nd.ch[k].hi[a] = t; }
     out[i] = nd;
 }
 
-hipError_t launch_order_nodes(const Bvh4Node* in, Bvh4Node* out, int num_nodes, const RootBox& root, const double point[3], bool far_first, hipStream_t stream) {
+hipError_t launch_order_nodes(const Bvh4Node* in, Bvh4Node* out, int num_nodes, const RootBox& root, const double point[3], bool far_first, int swap_mask, hipStream_t stream) {
     if (num_nodes <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_order_nodes, dim3((unsigned)((num_nodes + 255) / 256)), dim3(256), 0, stream, in, out, num_nodes,
-                       (float)(point[0] - root.centre[0]), (float)(point[1] - root.centre[1]), (float)(point[2] - root.centre[2]), far_first ? 1 : 0);
+                       (float)(point[0] - root.centre[0]), (float)(point[1] - root.centre[1]), (float)(point[2] - root.centre[2]), far_first ? 1 : 0, swap_mask);
     return hipGetLastError();
 }
 
@@ -2418,7 +2429,7 @@ template <int MODE, bool EXTRA, bool SUB, int PKT>
 static hipError_t launch_primary_p(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples, int pad_tiles) {
     // 1-D grid over the padded super-tile grid (see the tile order in k_primary)
     dim3 grid((unsigned)xcd_tile_grid(L.fc.width, row_count));
-    const int levels = PKT == 2 ? 3 * L.sc.b4depth + 2 : pipe_stack_levels(L.sc, MODE);
+    const int levels = PKT >= 2 ? 3 * L.sc.b4depth + 2 : pipe_stack_levels(L.sc, MODE);
     size_t lds = PKT ? (size_t)levels * 4 * 4 : (size_t)levels * 256 * 4;
     if (L.stats)
         hipLaunchKernelGGL((k_primary<MODE, EXTRA, true, SUB, PKT>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
@@ -2435,6 +2446,7 @@ static hipError_t launch_primary_s(const PipelineLaunch& L, int row_begin, int r
         // packet walk + camera-cone filter: the rays of the frame must share their origin (focal blur moves it per sub-sample)
         const bool common_origin = !(SUB && (L.fc.flags & 4u));
         if (L.sc.bcam && common_origin && !L.per_lane_primary) {
+            if (L.sc.b4cam && !L.bvh2_packets && L.sc.b4cam_known == 7) return launch_primary_p<MODE, EXTRA, SUB, 3>(L, row_begin, row_count, samples, pad_tiles);
             if (L.sc.b4cam && !L.bvh2_packets) return launch_primary_p<MODE, EXTRA, SUB, 2>(L, row_begin, row_count, samples, pad_tiles);
             return launch_primary_p<MODE, EXTRA, SUB, 1>(L, row_begin, row_count, samples, pad_tiles);
         }
@@ -2510,7 +2522,12 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
                 };
                 // 6 waves/SIMD (85 VGPRs): 5.16 ms on the headline frame; 7 waves (72 VGPRs, spills in the node step) 5.44; 5 waves 5.61
-                if (L.stats) go(k_shaft_pkt4<true, 6>); else go(k_shaft_pkt4<false, 6>);
+                // (one instantiation per set of axes on which the light lies outside the root box's slab: child_slabs<KNOWN>)
+                switch (L.sc.b4light_known & 7) {
+#define SR_GO(K) case K: if (L.stats) go(k_shaft_pkt4<true, 6, K>); else go(k_shaft_pkt4<false, 6, K>); break;
+                    SR_GO(0) SR_GO(1) SR_GO(2) SR_GO(3) SR_GO(4) SR_GO(5) SR_GO(6) SR_GO(7)
+#undef SR_GO
+                }
             } else if (first && !(L.per_lane_shaft & 1)) {
                 // round 1 on the binary tree (cross-check): one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
                 size_t lds = ((size_t)levels * 4 + (size_t)levels * 64 * 2) * 4;

@@ -555,15 +555,25 @@ __device__ bool bvh_packet_nearest(const DevScene& sc, int32_t* wnode, bool live
 // result are those of bvh_packet_nearest / bvh_intersect<false>: the nearest hit with the lowest-index tie-break does not
 // depend on the visiting order.  wnode: 3 * b4depth + 2 words.
 // --------------------------------------------------------------------------------------------------
+// KNOWN (bit a set): on axis a every ray of the frame that can reach the box meets the plane stored FIRST first -- the frame's ordered
+// copy of the nodes holds (near, far) instead of (lo, hi) there (k_order_nodes: the common origin / end of the rays lies outside the
+// root box's slab on that axis, so the sign of that direction component is the same for all of them) -- and the min / max of the two
+// plane parameters is not computed: 2 instead of 8 min/max per child when all three axes are known.  A ray whose component has the
+// other sign cannot reach any box of the scene; its "near" exceeds its "far" and the test fails, as it must.
+template <int KNOWN = 0>
 __device__ __forceinline__ void child_slabs(const Bvh4Child& ch, f2 I01, f2 I20, f2 I12, f2 B0, f2 B1, f2 B2, float& a, float& b) {
     const f2 T0 = pk_fma((f2){ch.lo[0], ch.lo[1]}, I01, B0), T1 = pk_fma((f2){ch.lo[2], ch.hi[0]}, I20, B1), T2 = pk_fma((f2){ch.hi[1], ch.hi[2]}, I12, B2);
-    a = fmaxf(fmaxf(fminf(T0.x, T1.y), fminf(T0.y, T2.x)), fminf(T1.x, T2.y));
-    b = fminf(fminf(fmaxf(T0.x, T1.y), fmaxf(T0.y, T2.x)), fmaxf(T1.x, T2.y));
+    // fminf/fmaxf drop a NaN operand: conservative
+    const float nx = (KNOWN & 1) ? T0.x : fminf(T0.x, T1.y), fx = (KNOWN & 1) ? T1.y : fmaxf(T0.x, T1.y);
+    const float ny = (KNOWN & 2) ? T0.y : fminf(T0.y, T2.x), fy = (KNOWN & 2) ? T2.x : fmaxf(T0.y, T2.x);
+    const float nz = (KNOWN & 4) ? T1.x : fminf(T1.x, T2.y), fz = (KNOWN & 4) ? T2.y : fmaxf(T1.x, T2.y);
+    a = fmaxf(fmaxf(nx, ny), nz);
+    b = fminf(fminf(fx, fy), fz);
 }
 // value k of four with a wave-uniform k (scalar selects / v_cndmask with scalar conditions: no indexed registers, no scratch)
 template <class T> __device__ __forceinline__ T pick4(int k, T a, T b, T c, T d) { return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d)); }
 
-template <bool FILTER>
+template <bool FILTER, int KNOWN>
 __device__ bool bvh4_packet_nearest(const DevScene& sc, int32_t* wnode, bool live, D3 s, D3 d, Hit& out, Ctr& c) {
     D3 end = s + d * 10000.0;
     D3 original = s;
@@ -589,10 +599,10 @@ __device__ bool bvh4_packet_nearest(const DevScene& sc, int32_t* wnode, bool liv
             const Bvh4Node n = sc.b4cam[ni];                           // wave-uniform address: scalar loads
             if (counter_lane) c.nodes++;                               // (per WAVE: 128-byte nodes fetched)
             float t0, x0, t1, x1, t2, x2, t3, x3;
-            child_slabs(n.ch[0], I01, I20, I12, B0, B1, B2, t0, x0);
-            child_slabs(n.ch[1], I01, I20, I12, B0, B1, B2, t1, x1);
-            child_slabs(n.ch[2], I01, I20, I12, B0, B1, B2, t2, x2);
-            child_slabs(n.ch[3], I01, I20, I12, B0, B1, B2, t3, x3);
+            child_slabs<KNOWN>(n.ch[0], I01, I20, I12, B0, B1, B2, t0, x0);
+            child_slabs<KNOWN>(n.ch[1], I01, I20, I12, B0, B1, B2, t1, x1);
+            child_slabs<KNOWN>(n.ch[2], I01, I20, I12, B0, B1, B2, t2, x2);
+            child_slabs<KNOWN>(n.ch[3], I01, I20, I12, B0, B1, B2, t3, x3);
             const bool h0 = act && n.ch[0].n >= 0 && t0 <= x0 && x0 >= 0.0f, h1 = act && n.ch[1].n >= 0 && t1 <= x1 && x1 >= 0.0f;
             const bool h2 = act && n.ch[2].n >= 0 && t2 <= x2 && x2 >= 0.0f, h3 = act && n.ch[3].n >= 0 && t3 <= x3 && x3 >= 0.0f;
             // ---- leaf children in slot order (front to back for this origin).  One copy of the triangle loop per slot, everything
@@ -653,7 +663,7 @@ __device__ bool bvh4_packet_nearest(const DevScene& sc, int32_t* wnode, bool liv
 
 // root of the chain for a wavefront of rays with a common origin: extra geometry per lane, then the packet walk
 // (WIDE: on the four-wide tree's camera-ordered copy)
-template <bool EXTRA, bool FILTER, bool WIDE = false>
+template <bool EXTRA, bool FILTER, int WIDE = 0>     // WIDE: 0 binary tree, 1 four-wide tree, 2 four-wide tree with (near, far) planes on all axes
 __device__ bool root_intersect_pkt(const DevScene& sc, const Rec128* extra, int32_t* wnode, bool live, D3 s, D3 d, Hit& out, Ctr& c) {
     bool any = false;
     double best = DBL_MAX;
@@ -674,7 +684,8 @@ __device__ bool root_intersect_pkt(const DevScene& sc, const Rec128* extra, int3
         }
     }
     Hit mh;
-    const bool model = WIDE ? bvh4_packet_nearest<FILTER>(sc, wnode, live, s, d, mh, c) : bvh_packet_nearest<FILTER>(sc, wnode, live, s, d, mh, c);
+    const bool model = WIDE == 2 ? bvh4_packet_nearest<FILTER, 7>(sc, wnode, live, s, d, mh, c)
+                     : (WIDE == 1 ? bvh4_packet_nearest<FILTER, 0>(sc, wnode, live, s, d, mh, c) : bvh_packet_nearest<FILTER>(sc, wnode, live, s, d, mh, c));
     if (model && mh.t < best) { out = mh; any = true; }
     return any;
 }
