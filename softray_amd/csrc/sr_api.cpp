@@ -500,13 +500,8 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             SR_HIP(before_rewrite());
             rewrote = true;
             s->b4light_valid = false;
-            int known, swap;                                      // (swap = the axes on which the light lies ABOVE the box)
-            point_outside_axes(s->root, fc.light_pos_model, known, swap);
-            if (s->dbg[SR_DBG_KERNEL_SWITCH] == 61) known = swap = 0;
-            // the shafts run from the surface points TOWARDS the light: on an axis where the light lies above the box they travel towards
-            // larger coordinates (lo first: no swap), where it lies below, towards smaller ones
-            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4light.p, (int)s->b4_num, s->root, fc.light_pos_model, true, known & ~swap & 7, stream));
-            s->b4light_known = known;
+            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4light.p, (int)s->b4_num, s->root, fc.light_pos_model, true, 0, stream));
+            s->b4light_known = 0;
             for (int i = 0; i < 3; ++i) s->b4_light[i] = fc.light_pos_model[i];
             s->b4light_valid = true;
         }

@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc
 // the candidate lists may differ in order and in which candidates a truncated list holds, which no later stage depends on.
 // LDS per wave: [levels] node words + [levels][64] 16-bit bounds, levels = 3 * b4depth + 2.
 // --------------------------------------------------------------------------------------------------
-template <bool STATS, int WAVES, int KNOWN>
+template <bool STATS, int WAVES>
 __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
                                                     const unsigned int* __restrict__ hit_count, int cap, int levels, int tile_n2, int tile_rows,
                                                     unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
@@ -923,10 +923,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameCon
     const float ix = slab_inv(dx), iy = slab_inv(dy), iz = slab_inv(dz);
     const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
     const f2 OI01 = {-ex * ix, -ey * iy}, OI20 = {-ez * iz, -ex * ix}, OI12 = {-ey * iy, -ez * iz};
-    // the box grows by r on every side: its near plane moves EARLIER, its far plane later.  Where the copy holds (lo, hi) that is
-    // -r i for lo and +r i for hi whatever the sign of i (the min / max sort it out); where it holds (near, far) it is -r |i| / +r |i|
-    const float rx = (KNOWN & 1) ? fabsf(ix) : ix, ry = (KNOWN & 2) ? fabsf(iy) : iy, rz = (KNOWN & 4) ? fabsf(iz) : iz;
-    const f2 RI01 = {-rx, -ry}, RI20 = {-rz, rx}, RI12 = {ry, rz};
+    const f2 RI01 = {-ix, -iy}, RI20 = {-iz, ix}, RI12 = {iy, iz};
     const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
     const ShaftRay sr = make_shaft_ray(sc, fc, E, lpos);
     int32_t* out = cand + (size_t)slot_i * cap;
@@ -955,10 +952,10 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameCon
         const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
         const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
         float a0, b0, a1, b1, a2, b2, a3, b3;                          // child u-intervals [a, b] of this lane's shaft
-        child_slabs<KNOWN>(n.ch[0], I01, I20, I12, B0, B1, B2, a0, b0);
-        child_slabs<KNOWN>(n.ch[1], I01, I20, I12, B0, B1, B2, a1, b1);
-        child_slabs<KNOWN>(n.ch[2], I01, I20, I12, B0, B1, B2, a2, b2);
-        child_slabs<KNOWN>(n.ch[3], I01, I20, I12, B0, B1, B2, a3, b3);
+        child_slabs(n.ch[0], I01, I20, I12, B0, B1, B2, a0, b0);
+        child_slabs(n.ch[1], I01, I20, I12, B0, B1, B2, a1, b1);
+        child_slabs(n.ch[2], I01, I20, I12, B0, B1, B2, a2, b2);
+        child_slabs(n.ch[3], I01, I20, I12, B0, B1, B2, a3, b3);
         b0 = fminf(b0, nu); b1 = fminf(b1, nu); b2 = fminf(b2, nu); b3 = fminf(b3, nu);
         const bool h0 = !done && n.ch[0].n >= 0 && fmaxf(a0, umin) <= b0, h1 = !done && n.ch[1].n >= 0 && fmaxf(a1, umin) <= b1;
         const bool h2 = !done && n.ch[2].n >= 0 && fmaxf(a2, umin) <= b2, h3 = !done && n.ch[3].n >= 0 && fmaxf(a3, umin) <= b3;
@@ -2522,12 +2519,9 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
                 };
                 // 6 waves/SIMD (85 VGPRs): 5.16 ms on the headline frame; 7 waves (72 VGPRs, spills in the node step) 5.44; 5 waves 5.61
-                // (one instantiation per set of axes on which the light lies outside the root box's slab: child_slabs<KNOWN>)
-                switch (L.sc.b4light_known & 7) {
-#define SR_GO(K) case K: if (L.stats) go(k_shaft_pkt4<true, 6, K>); else go(k_shaft_pkt4<false, 6, K>); break;
-                    SR_GO(0) SR_GO(1) SR_GO(2) SR_GO(3) SR_GO(4) SR_GO(5) SR_GO(6) SR_GO(7)
-#undef SR_GO
-                }
+                // ((near, far) planes in the light-ordered copy, as in the camera-ordered one, were measured: fewer instructions, more spills at
+                //  this kernel's register budget -- 5.17 -> 5.30 ms; 5.49 ms at 5 waves/SIMD)
+                if (L.stats) go(k_shaft_pkt4<true, 6>); else go(k_shaft_pkt4<false, 6>);
             } else if (first && !(L.per_lane_shaft & 1)) {
                 // round 1 on the binary tree (cross-check): one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
                 size_t lds = ((size_t)levels * 4 + (size_t)levels * 64 * 2) * 4;
