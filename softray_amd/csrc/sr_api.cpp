@@ -155,6 +155,8 @@ struct sr_scene {
 
 namespace {
 
+const int kMaxTreeDepth = 62;            // (depth + 2) stack levels x 256 lanes x 4 B = 64 KB of LDS per workgroup
+
 int use_device(sr_scene* s) {
     if (s->device < 0) return fail(SR_ERR_NO_DEVICE, "host-only scene: no HIP device bound (compute is never emulated on the CPU)");
     SR_HIP(hipSetDevice(s->device));
@@ -230,9 +232,14 @@ sr::DevScene dev_scene(const sr_scene* s) {
     d.bslab = (const sr::TriSlab*)s->d_bslab.p;
     d.bcam = s->cam_valid ? (const sr::CamCone*)s->d_bcam.p : nullptr;
     d.v9 = (const double*)s->d_v9.p;
-    d.b4 = s->b4_num > 0 ? (const sr::Bvh4Node*)s->d_b4.p : nullptr;
-    d.b4cam = (s->b4cam_valid && s->cam_valid) ? (const sr::Bvh4Node*)s->d_b4cam.p : nullptr;
-    d.b4light = s->b4light_valid ? (const sr::Bvh4Node*)s->d_b4light.p : nullptr;
+    // the four-wide walks stack up to three entries per level: a private walk needs (3 depth + 2) x 1 KB of LDS per workgroup, a packet
+    // walk (3 depth + 2) x 528 B; a tree too deep for that is walked in its binary form (a pathological scene, not a large one:
+    // 10 M triangles give depth 14)
+    const size_t lv4 = (size_t)(3 * s->b4_depth + 2);
+    const bool wide_private = s->b4_num > 0 && lv4 * 1024 <= 65536, wide_packets = s->b4_num > 0 && lv4 * 528 <= 65536;
+    d.b4 = wide_private ? (const sr::Bvh4Node*)s->d_b4.p : nullptr;
+    d.b4cam = (wide_packets && s->b4cam_valid && s->cam_valid) ? (const sr::Bvh4Node*)s->d_b4cam.p : nullptr;
+    d.b4light = (wide_packets && s->b4light_valid) ? (const sr::Bvh4Node*)s->d_b4light.p : nullptr;
     d.b4depth = s->b4_depth;
     d.b4cam_known = s->b4cam_known; d.b4light_known = s->b4light_known;
     d.bnode_bits = 1;
@@ -245,7 +252,8 @@ sr::DevScene dev_scene(const sr_scene* s) {
 int check_mode(const sr_scene* s, int mode) {
     if (!s->have_model || s->ntris == 0) return fail(SR_ERR_NO_MODEL, "no model: Render() returns without drawing (Renderer.cs:736-739)");
     if (mode == SR_MODE_REF_TREE && !s->ref.built) return fail(SR_ERR_NOT_BUILT, "SR_MODE_REF_TREE needs sr_build(1 << SR_MODE_REF_TREE)");
-    if (mode == SR_MODE_REF_TREE && s->ref.tree_depth > 120) return fail(SR_ERR_UNSUPPORTED, "reference tree deeper than 120 levels does not fit the LDS traversal stacks");
+    // one stack word per level and lane in LDS: (depth + 2) x 256 x 4 bytes must fit the 64 KB a workgroup may ask for
+    if (mode == SR_MODE_REF_TREE && s->ref.tree_depth > kMaxTreeDepth) return fail(SR_ERR_UNSUPPORTED, "reference tree deeper than 62 levels does not fit the LDS traversal stacks");
     if (mode == SR_MODE_BVH && !s->bvh.built) return fail(SR_ERR_NOT_BUILT, "SR_MODE_BVH needs sr_build(1 << SR_MODE_BVH)");
     if (mode != SR_MODE_REF_TREE && mode != SR_MODE_BRUTE && mode != SR_MODE_BVH) return fail(SR_ERR_INVALID_ARG, "unknown trace mode");
     return SR_OK;
@@ -974,7 +982,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
                                             s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(15, s->dbg[SR_DBG_BVH_LEAF]) : 0);
         d_slab.release();
         if (e != hipSuccess) return hip_fail(e, "build_bvh_device");
-        if (depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
+        if (depth > kMaxTreeDepth) return fail(SR_ERR_UNSUPPORTED, "BVH deeper than 62 levels does not fit the LDS traversal stacks");
         s->bvh = sr::Bvh();
         s->bvh.built = true;
         s->bvh.depth = depth;
@@ -997,7 +1005,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
     } else if (modes & (1u << SR_MODE_BVH)) {
         sr::build_bvh(s->v9, s->root, s->bvh, s->dbg[SR_DBG_BVH_LEAF] > 0 ? (int)std::min<int64_t>(15, s->dbg[SR_DBG_BVH_LEAF]) : 4,
                       s->dbg[SR_DBG_BUILD_THREADS] > 0 ? (int)std::min<int64_t>(64, s->dbg[SR_DBG_BUILD_THREADS]) : 0);
-        if (s->bvh.depth > 120) return fail(SR_ERR_UNSUPPORTED, "BVH too deep");
+        if (s->bvh.depth > kMaxTreeDepth) return fail(SR_ERR_UNSUPPORTED, "BVH deeper than 62 levels does not fit the LDS traversal stacks");
         s->bvh_on_device = false;
         s->bvh_dirty = true;
     }
