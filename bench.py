@@ -126,7 +126,7 @@ def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=30.0):
     depth 15 / 25 per leaf, row-block threads like Renderer.cs:1659-1670, timed on a CENTRED SQUARE CROP of the SAME frame
     (rows and columns windowed, same rays; BASELINE.md 3: 256^2 of the 4096^2 frame, smaller when the host's cores would need
     more than the budget) at threads = all host cores (the headline `value`) and at threads = 4 (rayTraceConcurrency's default,
-    Renderer.cs:82) on a 64^2 crop.  The round-2 sample -- a band of whole centre rows -- is kept as `sample_rows`."""
+    Renderer.cs:82) on a 128^2 (or 64^2) crop.  The round-2 sample -- a band of whole centre rows -- is kept as `sample_rows`."""
     from oracle import oracle_py as orc                              # the only place bench.py touches oracle/
     cores = host_cores()
     o = orc.Scene()
@@ -157,7 +157,8 @@ def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=30.0):
             v_all, rays_all, s_all = crop(side, cores)
             side_all = side
             break
-    v_4, rays_4, s_4 = crop(64, min(4, cores))
+    side_4 = 128 if s_all * (128.0 / side_all) ** 2 * cores / min(4, cores) <= budget_s else 64
+    v_4, rays_4, s_4 = crop(side_4, min(4, cores))
     # the round-2 sample: whole rows through the centre of the frame (the most expensive rows: every pixel hit and shadowed)
     f.start_row, f.end_row = mid - 1, mid
     t0 = time.time()
@@ -178,7 +179,7 @@ def cpu_baseline(args, v9, argb, bmin, bmax, budget_s=30.0):
             "sample": "centred %dx%d crop (rows and columns windowed) of the same %dx%d frame (%d primary rays, %.1f s); C++ restatement of "
                       "the reference algorithm (reference tree 15/25, row-block threads, g++ -O2 -ffp-contract=off) -- real C# unavailable; "
                       "tree build %.1f s excluded" % (side_all, side_all, args.res, args.res, rays_all, s_all, build_s),
-            "threads_4": {"value": v_4, "threads": min(4, cores), "sample": "centred 64x64 crop (%d primary rays, %.1f s)" % (rays_4, s_4),
+            "threads_4": {"value": v_4, "threads": min(4, cores), "sample": "centred %dx%d crop (%d primary rays, %.1f s)" % (side_4, side_4, rays_4, s_4),
                           "note": "rayTraceConcurrency's default (Renderer.cs:82)"},
             "sample_rows": {"value": rays_rows / s_rows / 1e6, "threads": cores,
                             "sample": "2 whole centre rows x %d cols (%d primary rays, %.1f s): the round-2 sample, biased low (every pixel of "
