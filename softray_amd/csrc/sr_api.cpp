@@ -91,6 +91,10 @@ struct sr_scene {
     int    b4_depth = 0;
     bool   b4cam_valid = false, b4light_valid = false;
     int    b4cam_known = 0, b4light_known = 0;   // axes on which the ordered copy holds (near, far) planes (sr_device.h)
+    // k_facing_partition: the leaves' records grouped by which of {camera rays, shadow sample rays} can hit them, for one (origin, light)
+    DBuf   d_rng_cam, d_rng_light;
+    bool   part_valid = false, part_cam = false, part_light = false;
+    double part_origin[3] = {0, 0, 0}, part_lightpos[3] = {0, 0, 0}, part_radius = 0;
     double b4_light[3] = {0, 0, 0};      // light position the order of d_b4light was made for
     // the per-origin / per-light records above are written on whatever stream the frame that needs them runs on: `pre_ready` is
     // recorded after every rewrite and waited for by every frame (another stream may use them next), `pre_used` is recorded at the
@@ -180,6 +184,7 @@ int upload_wide_tree(sr_scene* s, const sr::BvhNode* nodes, size_t num_nodes) {
     s->b4_depth = sr::collapse_bvh4(nodes, num_nodes, wide);
     s->b4_num = wide.size();
     s->b4cam_valid = s->b4light_valid = false;
+    s->part_valid = false;
     if (s->pre_used_set) SR_HIP(hipEventSynchronize(s->pre_used));       // a frame in flight may still be walking the old tree's copies
     SR_HIP(s->d_b4.upload(wide));
     SR_HIP(s->d_b4cam.reserve(wide.size() * sizeof(sr::Bvh4Node)));
@@ -477,7 +482,31 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         if (rewrote || !s->pre_used_set) return hipSuccess;
         return hipStreamWaitEvent(stream, s->pre_used, 0);
     };
-    if (f->trace_mode == SR_MODE_BVH && s->dbg[SR_DBG_PER_LANE_PRIMARY] <= 0 && !((f->flags & SR_F_FOCAL_BLUR) && f->sub_pixel_res > 1)) {
+    // ---- which records can the frame's camera rays / shadow sample rays hit at all?  (k_facing_partition, sr_pipeline.hip) ----
+    const bool pkt_primary = f->trace_mode == SR_MODE_BVH && s->dbg[SR_DBG_PER_LANE_PRIMARY] <= 0 && !((f->flags & SR_F_FOCAL_BLUR) && f->sub_pixel_res > 1);
+    const bool want_cam = wide && pkt_primary, want_light = wide && (fc.flags & SR_F_SHADOWS) && (fc.flags & SR_F_POINT_LIGHT);
+    if ((want_cam || want_light) && s->dbg[SR_DBG_KERNEL_SWITCH] != 71) {
+        const auto same3 = [](const double* a, const double* b) { return a[0] == b[0] && a[1] == b[1] && a[2] == b[2]; };
+        const bool cam_ok = !want_cam || (s->part_cam && same3(s->part_origin, fc.start_world));
+        const bool light_ok = !want_light || (s->part_light && same3(s->part_lightpos, fc.light_pos_model) && s->part_radius == fc.light_radius);
+        if (!s->part_valid || !cam_ok || !light_ok) {
+            SR_HIP(s->d_rng_cam.reserve(s->b4_num * 4 * 8));
+            SR_HIP(s->d_rng_light.reserve(s->b4_num * 4 * 8));
+            SR_HIP(before_rewrite());
+            rewrote = true;
+            s->part_valid = false;
+            s->cam_valid = false; s->b4cam_valid = false; s->b4light_valid = false;      // the records move: cone records and both copies are re-made
+            SR_HIP(sr::launch_facing_partition((const sr::Bvh4Node*)s->d_b4.p, (int)s->b4_num, (sr::Rec128*)s->d_btris.p, (sr::TriSlab*)s->d_bslab.p,
+                                               fc.start_world, want_cam, fc.light_pos_model, fc.light_radius, want_light, s->d_rng_cam.p, s->d_rng_light.p, stream));
+            s->part_cam = want_cam; s->part_light = want_light;
+            for (int i = 0; i < 3; ++i) { s->part_origin[i] = fc.start_world[i]; s->part_lightpos[i] = fc.light_pos_model[i]; }
+            s->part_radius = fc.light_radius;
+            s->part_valid = true;
+        }
+    } else if (s->part_valid && s->dbg[SR_DBG_KERNEL_SWITCH] == 71) {
+        s->part_valid = false; s->b4cam_valid = false; s->b4light_valid = false;        // (hook: no live runs -- the copies are re-made without them)
+    }
+    if (pkt_primary) {
         const size_t nt = s->ntris;
         const bool same_origin = s->cam_origin[0] == fc.start_world[0] && s->cam_origin[1] == fc.start_world[1] && s->cam_origin[2] == fc.start_world[2];
         if (!s->cam_valid || !same_origin) {
@@ -497,7 +526,8 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             point_outside_axes(s->root, fc.start_world, known, swap);
             // the camera-ordered copy holds (near, far) planes only when that is true on ALL axes (one extra instantiation of k_primary, not seven)
             if (known != 7 || s->dbg[SR_DBG_KERNEL_SWITCH] == 61) known = swap = 0;
-            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4cam.p, (int)s->b4_num, s->root, fc.start_world, false, swap, stream));
+            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4cam.p, (int)s->b4_num, s->root, fc.start_world, false, swap,
+                                          (s->part_valid && s->part_cam) ? s->d_rng_cam.p : nullptr, stream));
             s->b4cam_known = known;
             s->b4cam_valid = true;
         }
@@ -508,7 +538,8 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             SR_HIP(before_rewrite());
             rewrote = true;
             s->b4light_valid = false;
-            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4light.p, (int)s->b4_num, s->root, fc.light_pos_model, true, 0, stream));
+            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4light.p, (int)s->b4_num, s->root, fc.light_pos_model, true, 0,
+                                          (s->part_valid && s->part_light) ? s->d_rng_light.p : nullptr, stream));
             s->b4light_known = 0;
             for (int i = 0; i < 3; ++i) s->b4_light[i] = fc.light_pos_model[i];
             s->b4light_valid = true;
@@ -841,7 +872,7 @@ void sr_destroy(sr_scene* s) {
     }
     if (s->device >= 0 && hipSetDevice(s->device) == hipSuccess) {
         DBuf* bufs[] = {&s->d_tris, &s->d_extra, &s->d_rnodes, &s->d_rboxes, &s->d_rleaf, &s->d_bnodes, &s->d_btris, &s->d_bslab,
-                        &s->d_v9, &s->d_bcam, &s->d_b4, &s->d_b4cam, &s->d_b4light, &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_pixels, &s->d_aa, &s->d_stats};
+                        &s->d_v9, &s->d_bcam, &s->d_b4, &s->d_b4cam, &s->d_b4light, &s->d_rng_cam, &s->d_rng_light, &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_pixels, &s->d_aa, &s->d_stats};
         for (DBuf* b : bufs) b->release();
         for (auto& sc : s->scratch) sc.release();
         for (auto& t : s->tables) { t.dev.release(); if (t.host) (void)hipHostFree(t.host); if (t.used) (void)hipEventDestroy(t.used); }
@@ -993,6 +1024,7 @@ int sr_build(sr_scene* s, uint32_t modes, int32_t max_depth, int32_t max_per_lea
         {   // the four-wide tree of the packet walks, collapsed where the binary nodes are
             if (s->pre_used_set) SR_HIP(hipEventSynchronize(s->pre_used));      // a frame in flight may still be walking the old tree's copies
             s->b4cam_valid = s->b4light_valid = false;
+            s->part_valid = false;
             SR_HIP(s->d_b4.reserve((size_t)nn * sizeof(sr::Bvh4Node)));
             int n4 = 0, d4 = 0;
             e = sr::collapse_bvh4_device((const sr::BvhNode*)s->d_bnodes.p, nn, (sr::Bvh4Node*)s->d_b4.p, &n4, &d4, nullptr);

@@ -112,7 +112,14 @@ hipError_t launch_pipeline(const PipelineLaunch& L);
 // per-frame pre-pass: a copy of the four-wide nodes with every node's children sorted by the distance of their box centres from
 // `point` (model space), nearest first (camera origin) or farthest first (light: nearest to the surface points first)
 // swap_mask (bit a): exchange lo and hi on axis a in the copy (the rays of the frame travel towards smaller coordinates there)
-hipError_t launch_order_nodes(const Bvh4Node* in, Bvh4Node* out, int num_nodes, const RootBox& root, const double point[3], bool far_first, int swap_mask, hipStream_t stream);
+// live_runs (nullable): int2 per (node, slot) from launch_facing_partition -- the (offset, count) of a leaf's records that rays of this
+// copy can hit
+hipError_t launch_order_nodes(const Bvh4Node* in, Bvh4Node* out, int num_nodes, const RootBox& root, const double point[3], bool far_first, int swap_mask,
+                              const void* live_runs, hipStream_t stream);
+// per (camera origin, light) pre-pass: re-orders the records of every leaf in place so that the records a camera ray / a shadow sample ray
+// can hit (the triangle faces the origin / the light) are contiguous, and writes their (offset, count) per (node, slot) (int2 each)
+hipError_t launch_facing_partition(const Bvh4Node* base, int num_nodes, Rec128* btris, TriSlab* bslab, const double origin[3], bool use_cam,
+                                   const double light[3], double light_radius, bool use_light, void* cam_rng, void* light_rng, hipStream_t stream);
 // per-frame pre-pass: camera-cone records of every BVH triangle for the ray origin `origin` (model space)
 hipError_t launch_cam_cones(const DevScene& sc, int ntris, const double origin[3], CamCone* out, hipStream_t stream);
 size_t pipeline_hit_record_bytes();

@@ -2366,11 +2366,76 @@ __global__ __launch_bounds__(256) void k_cam_cones(const Rec128* __restrict__ bt
 // Links are untouched (a child keeps its node index), only the slots move; the sort is stable, so equal keys keep build order.
 // 128 B read + 128 B written per node: 17 MB at 1 M triangles; re-run only when the point or the tree changed.
 // --------------------------------------------------------------------------------------------------
+// --------------------------------------------------------------------------------------------------
+// k_facing_partition: per (camera origin, light) pre-pass of the packet walks.  Triangle.IntersectRay is one-sided: a ray can only
+// hit a triangle whose plane it starts in front of and runs towards (Plane.cs:52-75: dirDist < 0, originDist - startDist <= 0), so
+//   * a triangle with n.O - d < 0 cannot be hit by ANY ray that starts at the camera origin O ("camera-dead"), and
+//   * a triangle with n.L - d + R < 0 cannot be hit by any sample ray that starts within R of the light L ("light-dead")
+// (both from the FP64 plane of the record the exact test itself uses, with a 1e-9 margin).  About half of a scene's triangles are
+// dead for the camera and half for the light.  The records of every leaf are re-ordered IN PLACE (FP64 record and TriSlab together;
+// a leaf keeps its range, so every other walk is unaffected) into four groups -- (camera-dead, light-live), (both live),
+// (camera-live, light-dead), (both dead) -- so that the camera-live records and the light-live records are each one contiguous
+// run; the two runs (offset, count) per leaf slot go to side arrays that k_order_nodes applies to the camera- / light-ordered copy.
+// The packet walks then never fetch a dead record, and leaves without a live record become empty slots.  One thread per
+// (node, slot); the camera-cone records are re-made afterwards (they follow the records' positions).
+// --------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_facing_partition(const Bvh4Node* __restrict__ base, int n4, Rec128* __restrict__ btris, TriSlab* __restrict__ bslab,
+                                                          double ox, double oy, double oz, int use_cam, double lx, double ly, double lz, double R, int use_light,
+                                                          int2* __restrict__ cam_rng, int2* __restrict__ light_rng) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n4 * 4) return;
+    const Bvh4Child ch = base[t >> 2].ch[t & 3];
+    if (ch.n <= 0) { cam_rng[t] = make_int2(0, ch.n); light_rng[t] = make_int2(0, ch.n); return; }
+    const int c = ch.c, n = ch.n;
+    const auto group = [&](int k) {
+        const double* p = btris[k].p;
+        const double mag = 1e-9 * (1.0 + fabs(p[3]) + fabs(ox) + fabs(oy) + fabs(oz) + fabs(lx) + fabs(ly) + fabs(lz));
+        const bool cam_dead = use_cam && (p[0] * ox + p[1] * oy + p[2] * oz - p[3]) < -mag;
+        const bool light_dead = use_light && (p[0] * lx + p[1] * ly + p[2] * lz - p[3]) + R * 1.000001 < -mag;
+        return cam_dead ? (light_dead ? 3 : 0) : (light_dead ? 2 : 1);
+    };
+    int pos = c, cnt[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {                                        // (what is left after three passes is group 3)
+        for (int k = pos; k < c + n; ++k) {
+            if (group(k) != g) continue;
+            if (k != pos) {
+                uint4* a = reinterpret_cast<uint4*>(&btris[k]); uint4* b = reinterpret_cast<uint4*>(&btris[pos]);
+                for (int w = 0; w < 8; ++w) { const uint4 x = a[w]; a[w] = b[w]; b[w] = x; }
+                uint4* sa_ = reinterpret_cast<uint4*>(&bslab[k]); uint4* sb_ = reinterpret_cast<uint4*>(&bslab[pos]);
+                for (int w = 0; w < 4; ++w) { const uint4 x = sa_[w]; sa_[w] = sb_[w]; sb_[w] = x; }
+            }
+            ++pos;
+            if (g == 0) cnt[0]++; else if (g == 1) cnt[1]++; else cnt[2]++;
+        }
+    }
+    cam_rng[t] = make_int2(cnt[0], cnt[1] + cnt[2]);
+    light_rng[t] = make_int2(0, cnt[0] + cnt[1]);
+}
+
+hipError_t launch_facing_partition(const Bvh4Node* base, int num_nodes, Rec128* btris, TriSlab* bslab, const double origin[3], bool use_cam,
+                                   const double light[3], double light_radius, bool use_light, void* cam_rng, void* light_rng, hipStream_t stream) {
+    if (num_nodes <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_facing_partition, dim3((unsigned)((num_nodes * 4 + 255) / 256)), dim3(256), 0, stream, base, num_nodes, btris, bslab,
+                       origin[0], origin[1], origin[2], use_cam ? 1 : 0, light[0], light[1], light[2], light_radius, use_light ? 1 : 0, (int2*)cam_rng, (int2*)light_rng);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void k_order_nodes(const Bvh4Node* __restrict__ in, Bvh4Node* __restrict__ out, int n, float px, float py, float pz, int far_first,
-                                                     int swap_mask) {
+                                                     int swap_mask, const int2* __restrict__ rng) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     Bvh4Node nd = in[i];
+    if (rng) {                                                           // the live run of every leaf for this copy's rays (k_facing_partition)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (nd.ch[k].n > 0) {
+                const int2 r = rng[i * 4 + k];
+                nd.ch[k].c += r.x;
+                nd.ch[k].n = r.y > 0 ? r.y : -1;
+            }
+        }
+    }
     float key[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -2399,10 +2464,12 @@ __global__ __launch_bounds__(256) void k_order_nodes(const Bvh4Node* __restrict_
     out[i] = nd;
 }
 
-hipError_t launch_order_nodes(const Bvh4Node* in, Bvh4Node* out, int num_nodes, const RootBox& root, const double point[3], bool far_first, int swap_mask, hipStream_t stream) {
+hipError_t launch_order_nodes(const Bvh4Node* in, Bvh4Node* out, int num_nodes, const RootBox& root, const double point[3], bool far_first, int swap_mask,
+                              const void* live_runs, hipStream_t stream) {
     if (num_nodes <= 0) return hipSuccess;
     hipLaunchKernelGGL(k_order_nodes, dim3((unsigned)((num_nodes + 255) / 256)), dim3(256), 0, stream, in, out, num_nodes,
-                       (float)(point[0] - root.centre[0]), (float)(point[1] - root.centre[1]), (float)(point[2] - root.centre[2]), far_first ? 1 : 0, swap_mask);
+                       (float)(point[0] - root.centre[0]), (float)(point[1] - root.centre[1]), (float)(point[2] - root.centre[2]), far_first ? 1 : 0, swap_mask,
+                       (const int2*)live_runs);
     return hipGetLastError();
 }
 
