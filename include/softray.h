@@ -222,7 +222,9 @@ int  sr_reset_shadow_cache(sr_scene*);
 /* Same, but `d_pixels` is DEVICE memory on the scene's device (e.g. a torch tensor's data_ptr) and the
  * work is enqueued on `hip_stream` (a hipStream_t; NULL = the null stream) without host sync. */
 /* Ordering: the work is enqueued behind everything already on `hip_stream` and `hip_stream` continues only after it; a
- * shadowed frame is internally forked onto two library-owned streams (event fork / join), see SR_F_NO_SPLIT. */
+ * shadowed frame is internally forked onto two library-owned streams (event fork / join), see SR_F_NO_SPLIT.  Frames of ONE scene
+ * run in submission order whatever streams they are given (the scene's scratch and its per-camera / per-light records belong to one
+ * frame at a time: a frame's stream waits for an event the previous frame of the scene left behind); to overlap frames, use scenes. */
 int  sr_render_device(sr_scene*, const sr_frame*, void* d_pixels, void* hip_stream, uint64_t* d_stats /* device uint64[SR_STATS_COUNT] (see sr_last_ray_stats) or NULL */);
 /* number of int32 pixels sr_render writes for this frame (W*H, or the compact strip size) */
 int64_t sr_frame_pixel_count(const sr_frame*);
@@ -316,7 +318,9 @@ enum {
     SR_DBG_SPLIT          = 3,   /* concurrent part-frame pipelines (default 2, <= 4)                                          */
     SR_DBG_FB_RAY_CAP     = 4,   /* capacity of the fallback ray list                                                          */
     SR_DBG_BVH_LEAF       = 5,   /* triangles per leaf of the own BVH, host and device build (default 4, 1..15); read by the next sr_build */
-    SR_DBG_KERNEL_SWITCH  = 6,   /* FrameConst.debug: kernel-internal experiment switch (0 = production)                       */
+    SR_DBG_KERNEL_SWITCH  = 6,   /* A/B switch of single optimisations, same pixels (0 = production): 31 the bounce pipeline walks its rays in
+                                    queue order (no per-level ray sort); 61 the camera-ordered node copy keeps (lo, hi) planes; 71 no facing
+                                    partition (the packet walks see every record of a leaf); 7 counts umbra decisions of the private shaft walk */
     SR_DBG_KERNEL_TIMING  = 7,   /* > 0: record a HIP event pair around every launch (sr_kernel_times); default off           */
     SR_DBG_EXACT_SHADOW_TESTS = 8, /* > 0: k_shadow_test decides every (sample, triangle) pair with the FP64 arithmetic (no
                                     fp32 classification): an independent schedule of the same result, kept as a cross-check */

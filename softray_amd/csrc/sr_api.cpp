@@ -110,6 +110,7 @@ struct sr_scene {
         void* host = nullptr; size_t host_cap = 0;
         DBuf  dev;
         hipEvent_t used = nullptr; bool in_flight = false;
+        hipEvent_t ready = nullptr; bool ready_set = false;       // recorded after the upload: a frame on ANOTHER stream that reuses the slot waits for it
         size_t off_bytes = 0, map_bytes = 0;
     } tables[2];
     int tables_cur = 0;
@@ -381,6 +382,17 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     if (rc) return rc;
     if ((rc = sync_geometry(s, (uint32_t)f->trace_mode))) return rc;
     if (fc.num_rows == 0) return SR_OK;
+    // ---- frames of one scene run in submission order whatever streams they are given: the scene's scratch (hit queues, candidate
+    //      lists, counters) and its per-origin / per-light records belong to one frame at a time.  `pre_used` is recorded when everything
+    //      a frame enqueues is on its stream; the next frame's stream waits for it (a no-op on the same stream) ----
+    if (s->pre_used_set) SR_HIP(hipStreamWaitEvent(stream, s->pre_used, 0));
+    struct MarkPreUsed {
+        sr_scene* s; hipStream_t st;
+        ~MarkPreUsed() {
+            if (!s->pre_used && hipEventCreateWithFlags(&s->pre_used, hipEventDisableTiming) != hipSuccess) return;
+            if (hipEventRecord(s->pre_used, st) == hipSuccess) s->pre_used_set = true;
+        }
+    } mark_pre_used{s, stream};
     // ---- frame tables -> device ----
     const size_t off_bytes = (s->offsets_host.size() * sizeof(double) + 255) / 256 * 256, map_bytes = s->rowmap_host.size() * sizeof(int32_t);
     {
@@ -404,7 +416,12 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             std::memcpy((char*)T->host + off_bytes, s->rowmap_host.data(), map_bytes);
             T->off_bytes = off_bytes; T->map_bytes = map_bytes;
             SR_HIP(hipMemcpyAsync(T->dev.p, T->host, need, hipMemcpyHostToDevice, stream));
+            if (!T->ready) SR_HIP(hipEventCreateWithFlags(&T->ready, hipEventDisableTiming));
+            SR_HIP(hipEventRecord(T->ready, stream));
+            T->ready_set = true;
             s->tables_valid = true;
+        } else if (T->ready_set) {
+            SR_HIP(hipStreamWaitEvent(stream, T->ready, 0));        // uploaded on another stream, perhaps
         }
     }
     sr_scene::FrameTables& FT = s->tables[s->tables_cur];
@@ -552,13 +569,6 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     } else if (s->pre_ready_set) {
         SR_HIP(hipStreamWaitEvent(stream, s->pre_ready, 0));          // written on another stream, perhaps: order this frame after it
     }
-    struct MarkPreUsed {                                              // recorded when everything this frame enqueues is on the stream
-        sr_scene* s; hipStream_t st;
-        ~MarkPreUsed() {
-            if (!s->pre_used && hipEventCreateWithFlags(&s->pre_used, hipEventDisableTiming) != hipSuccess) return;
-            if (hipEventRecord(s->pre_used, st) == hipSuccess) s->pre_used_set = true;
-        }
-    } mark_pre_used{s, stream};
     // ---- default: the primary / shadow / resolve pipeline, in row bands ----
     const long long n2 = (long long)fc.sub_pixel_res * fc.sub_pixel_res;
     const bool shadows = (fc.flags & SR_F_SHADOWS) != 0;
@@ -875,7 +885,7 @@ void sr_destroy(sr_scene* s) {
                         &s->d_v9, &s->d_bcam, &s->d_b4, &s->d_b4cam, &s->d_b4light, &s->d_rng_cam, &s->d_rng_light, &s->d_shadow_cache, &s->d_static_claim, &s->d_static_hits, &s->d_pixels, &s->d_aa, &s->d_stats};
         for (DBuf* b : bufs) b->release();
         for (auto& sc : s->scratch) sc.release();
-        for (auto& t : s->tables) { t.dev.release(); if (t.host) (void)hipHostFree(t.host); if (t.used) (void)hipEventDestroy(t.used); }
+        for (auto& t : s->tables) { t.dev.release(); if (t.host) (void)hipHostFree(t.host); if (t.used) (void)hipEventDestroy(t.used); if (t.ready) (void)hipEventDestroy(t.ready); }
         if (s->fork) (void)hipEventDestroy(s->fork);
         if (s->io_stream) (void)hipStreamDestroy(s->io_stream);
         if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);

@@ -627,6 +627,36 @@ def test_multi_device_scene_over_distinct_gpus():
     multi.close()
 
 
+def test_frames_on_two_streams_without_host_syncs():
+    """sr_render_device accepts any stream.  The per-origin / per-light records (facing partition, camera cones, ordered node copies) and
+    the frame tables are written on whatever stream the frame that needs them runs on and are reused by later frames: frames with
+    different cameras, lights and sample tables alternate between two streams with no host synchronisation in between -- the library
+    orders them with events -- and every one must equal its blocking render."""
+    import torch
+    v9, argb, bmin, bmax = unit_cube_scene(60000)
+    g = sa.GpuScene(0)
+    g.set_triangles(v9, argb, bmin, bmax)
+    g.build((sa.MODE_BVH,))
+    dev = torch.device("cuda", 0)
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    frames = []
+    for k in range(8):
+        f = as_sr(make_frame(200, 160, depth=1.5, shadows=True, yaw_deg=135.0 + 17.0 * (k % 4), pitch_deg=-22.0 + 9.0 * (k // 4),
+                             shadow_samples=(100, 37)[k % 2]), sa.MODE_BVH)
+        if k % 3 == 2:
+            f.light_pos_view[0] += 0.4
+        frames.append(f)
+    want = [g.render(f, stats=False)[0].copy() for f in frames]
+    torch.cuda.synchronize(dev)
+    outs = [torch.zeros(200 * 160, dtype=torch.int32, device=dev) for _ in frames]
+    for rep in range(2):
+        for k, f in enumerate(frames):
+            g.render_device(f, outs[k].data_ptr(), streams[k % 2].cuda_stream)
+    torch.cuda.synchronize(dev)
+    for k in range(len(frames)):
+        assert np.array_equal(outs[k].cpu().numpy().view(np.uint32), want[k]), k
+
+
 def test_full_size_properties():
     """BASELINE-size checks (1 M triangles, up to 4096^2) through size-independent properties: the three shadow schedules
     agree, the union of interleaved strips is the frame, rendering is idempotent, the own BVH and the literal reference
