@@ -2061,10 +2061,50 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
     int32_t ni = -1, leafA = -1, leafB = -1;
     int32_t leafC = -1, leafD = -1;            // (WIDE) a four-wide node can leave four pending leaves; the queue fills from leafA
     bool active = false, walking = false;
+    bool finished = false;                     // the walk of this lane's ray is over; its colour and its next ray are made at the next refill
     bool drained = false;
     for (;;) {
         const unsigned long long busy = __ballot(active);
-        if (!drained && (int)__popcll(busy) <= kRaysRefillAt) {
+        const bool refill_now = (int)__popcll(busy) <= kRaysRefillAt;
+        // ---- the finished rays of the wave, TOGETHER (shading, level colour, next reflection): done whenever one lane's walk ended, this
+        //      block -- a pow(), a dozen FP64 products, a queue append -- ran once per ray at one or two lanes; at the refill points it runs
+        //      once per ~24 rays at ~24 lanes ----
+        if (refill_now && __any(finished)) {
+            if (finished) {
+                bool hit = false;
+                D3 hpos = ex_pos, hnrm = ex_nrm;
+                uint32_t hcol = ex_color;
+                if (ex_t < DBL_MAX) hit = true;
+                if (walking && bestK >= 0 && (best + offset) < ex_t) {
+                    const Rec128* r = &sc.btris[bestK];
+                    hit = true;
+                    hpos = s + d * best;
+                    hnrm = mk(r->p[0], r->p[1], r->p[2]);
+                    hcol = r->color;
+                }
+                if (hit) {
+                    uint32_t color = hcol;
+                    if (fc.flags & 1u) color = shade(fc, hpos, hnrm, color);
+                    levels[(size_t)sample * (size_t)(maxb + 1) + level] = color;
+                    const uint32_t nl = level + 1u;
+                    if ((int)nl > maxb) {
+                        nlev[sample] = (uint8_t)(nl | 0x80u);                  // the deepest level is a surface: nothing beyond it
+                    } else {
+                        nlev[sample] = (uint8_t)nl;
+                        HitRec o;
+                        const D3 refl = d - hnrm * (2.0 * dot(d, hnrm));
+                        const D3 org = hpos + hnrm * 0.001;
+                        o.pos[0] = org.x; o.pos[1] = org.y; o.pos[2] = org.z;
+                        o.nrm[0] = refl.x; o.nrm[1] = refl.y; o.nrm[2] = refl.z;
+                        o.sample = sample;
+                        o.pad[0] = nl; o.pad[1] = o.pad[2] = 0;
+                        qout[atomicAdd(qout_count, 1u)] = o;                   // the compiler aggregates this per wavefront
+                    }
+                }
+                finished = false;
+            }
+        }
+        if (!drained && refill_now) {
             const unsigned long long m = ~busy;
             unsigned int base = 0;
             const int leader = __ffsll((long long)m) - 1;
@@ -2114,7 +2154,10 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
                 }
             }
         }
-        if (!__any(active)) break;
+        if (!__any(active)) {
+            if (__any(finished)) continue;                        // (drained: the last rays are resolved at the top of the loop)
+            break;
+        }
         if (active) {
             while (WIDE && ni >= 0 && leafA < 0) {
                 const Bvh4Node n = sc.b4[ni];
@@ -2189,38 +2232,8 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
                     }
                 }
             }
-            if (ni < 0 && leafA < 0) {
-                // ---- the ray is finished: nearest of {extras, model}, colour of this level, next reflection ----
-                bool hit = false;
-                D3 hpos = ex_pos, hnrm = ex_nrm;
-                uint32_t hcol = ex_color;
-                if (ex_t < DBL_MAX) hit = true;
-                if (walking && bestK >= 0 && (best + offset) < ex_t) {
-                    const Rec128* r = &sc.btris[bestK];
-                    hit = true;
-                    hpos = s + d * best;
-                    hnrm = mk(r->p[0], r->p[1], r->p[2]);
-                    hcol = r->color;
-                }
-                if (hit) {
-                    uint32_t color = hcol;
-                    if (fc.flags & 1u) color = shade(fc, hpos, hnrm, color);
-                    levels[(size_t)sample * (size_t)(maxb + 1) + level] = color;
-                    const uint32_t nl = level + 1u;
-                    if ((int)nl > maxb) {
-                        nlev[sample] = (uint8_t)(nl | 0x80u);                  // the deepest level is a surface: nothing beyond it
-                    } else {
-                        nlev[sample] = (uint8_t)nl;
-                        HitRec o;
-                        const D3 refl = d - hnrm * (2.0 * dot(d, hnrm));
-                        const D3 org = hpos + hnrm * 0.001;
-                        o.pos[0] = org.x; o.pos[1] = org.y; o.pos[2] = org.z;
-                        o.nrm[0] = refl.x; o.nrm[1] = refl.y; o.nrm[2] = refl.z;
-                        o.sample = sample;
-                        o.pad[0] = nl; o.pad[1] = o.pad[2] = 0;
-                        qout[atomicAdd(qout_count, 1u)] = o;                   // the compiler aggregates this per wavefront
-                    }
-                }
+            if (ni < 0 && leafA < 0) {                            // the walk is over: the ray waits for the wave's next refill point
+                finished = true;
                 active = false;
             }
         }
