@@ -1806,6 +1806,7 @@ __global__ __launch_bounds__(256) void k_fb_expand(const unsigned int* __restric
 }
 
 constexpr int kRaysRefillAt = 40;        // k_shadow_rays fetches new rays when at most this many lanes are still walking
+constexpr int kBounceRefillAt = 8;       // k_bounce: ... and resolves its finished rays
 
 // Persistent lanes with refill: the rays of this list belong to different hit points and end after very different numbers
 // of steps (most are blocked early, the lit ones walk the whole ray), so with one ray per lane 8 of 64 lanes were busy on
@@ -2065,7 +2066,9 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
     bool drained = false;
     for (;;) {
         const unsigned long long busy = __ballot(active);
-        const bool refill_now = (int)__popcll(busy) <= kRaysRefillAt;
+        // (k_shadow_rays refills at 40 busy lanes; here every refill also runs the FP64 clip of the new rays and the shading of the finished
+        //  ones for the whole wave, so fewer, fuller batches win: 56: 78 ms, 40: 62, 24: 59, 16: 57, 8: 56.2, 4: 56.3, 0: 57.6 at C5)
+        const bool refill_now = (int)__popcll(busy) <= kBounceRefillAt;
         // ---- the finished rays of the wave, TOGETHER (shading, level colour, next reflection): done whenever one lane's walk ended, this
         //      block -- a pow(), a dozen FP64 products, a queue append -- ran once per ray at one or two lanes; at the refill points it runs
         //      once per ~24 rays at ~24 lanes ----
