@@ -63,7 +63,6 @@ struct sr_scene {
     // sr_create_multi: this scene only dispatches to one complete scene per device (the model is replicated, a frame is split
     // into interleaved 16-row strips); empty for an ordinary scene
     std::vector<sr_scene*> parts;
-    DBuf d_gather;                         // (dispatcher) unused; parts render into their own d_pixels
     // host copies (what Renderer keeps between frames)
     std::vector<double>   v9;
     std::vector<uint32_t> argb;
@@ -494,11 +493,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     if (shadows_on_bvh && (rc = sync_geometry(s, SR_MODE_BVH))) return rc;
     const bool bvh_walks = f->trace_mode == SR_MODE_BVH || shadows_on_bvh;
     const bool wide = bvh_walks && s->b4_num > 0 && s->dbg[SR_DBG_BVH2_PACKETS] <= 0;
-    bool rewrote = false;
-    auto before_rewrite = [&]() -> hipError_t {                       // frames enqueued earlier (any stream) may still read the old records
-        if (rewrote || !s->pre_used_set) return hipSuccess;
-        return hipStreamWaitEvent(stream, s->pre_used, 0);
-    };
+    bool rewrote = false;                                             // (frames enqueued earlier have been waited for: see pre_used above)
     // ---- which records can the frame's camera rays / shadow sample rays hit at all?  (k_facing_partition, sr_pipeline.hip) ----
     const bool pkt_primary = f->trace_mode == SR_MODE_BVH && s->dbg[SR_DBG_PER_LANE_PRIMARY] <= 0 && !((f->flags & SR_F_FOCAL_BLUR) && f->sub_pixel_res > 1);
     const bool want_cam = wide && pkt_primary, want_light = wide && (fc.flags & SR_F_SHADOWS) && (fc.flags & SR_F_POINT_LIGHT);
@@ -509,7 +504,6 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         if (!s->part_valid || !cam_ok || !light_ok) {
             SR_HIP(s->d_rng_cam.reserve(s->b4_num * 4 * 8));
             SR_HIP(s->d_rng_light.reserve(s->b4_num * 4 * 8));
-            SR_HIP(before_rewrite());
             rewrote = true;
             s->part_valid = false;
             s->cam_valid = false; s->b4cam_valid = false; s->b4light_valid = false;      // the records move: cone records and both copies are re-made
@@ -528,7 +522,6 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         const bool same_origin = s->cam_origin[0] == fc.start_world[0] && s->cam_origin[1] == fc.start_world[1] && s->cam_origin[2] == fc.start_world[2];
         if (!s->cam_valid || !same_origin) {
             SR_HIP(s->d_bcam.reserve(nt * sizeof(sr::CamCone)));
-            SR_HIP(before_rewrite());
             rewrote = true;
             s->cam_valid = false;
             s->b4cam_valid = false;
@@ -537,7 +530,6 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             s->cam_valid = true;
         }
         if (wide && !s->b4cam_valid) {                                // the four-wide nodes, children front to back for this origin
-            SR_HIP(before_rewrite());
             rewrote = true;
             int known, swap;                                      // (a camera ABOVE the box on an axis looks towards smaller coordinates: hi first)
             point_outside_axes(s->root, fc.start_world, known, swap);
@@ -552,7 +544,6 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     if (wide && (fc.flags & SR_F_SHADOWS) && (fc.flags & SR_F_POINT_LIGHT)) {
         const bool same_light = s->b4_light[0] == fc.light_pos_model[0] && s->b4_light[1] == fc.light_pos_model[1] && s->b4_light[2] == fc.light_pos_model[2];
         if (!s->b4light_valid || !same_light) {                       // ... and nearest-to-the-surface first for this light
-            SR_HIP(before_rewrite());
             rewrote = true;
             s->b4light_valid = false;
             SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4light.p, (int)s->b4_num, s->root, fc.light_pos_model, true, 0,
