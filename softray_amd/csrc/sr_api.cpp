@@ -119,12 +119,13 @@ struct sr_scene {
     static constexpr int kMaxSplit = 4;
     struct BandScratch {
         DBuf hits, hits2, bounce_levels, bounce_nlev, samples, counters, fallback, fallback_state, fallback_rays, fallback_ovf, ray_sort, ray_sort_temp;
+        DBuf accum;                        // escape counts per sample index of a chunked (> 128 samples) shadow stage; zero between frames
         DBuf rlist[sr::kShaftRounds], rstate[sr::kShaftRounds], rcount[sr::kShaftRounds], rcand[sr::kShaftRounds];
         hipStream_t stream = nullptr;
         hipEvent_t  done = nullptr;
         bool used_last_frame = false;
         void release() {
-            DBuf* b[] = {&hits, &hits2, &bounce_levels, &bounce_nlev, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf, &ray_sort, &ray_sort_temp};
+            DBuf* b[] = {&hits, &hits2, &bounce_levels, &bounce_nlev, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf, &ray_sort, &ray_sort_temp, &accum};
             for (DBuf* x : b) x->release();
             for (int r = 0; r < sr::kShaftRounds; ++r) { rlist[r].release(); rstate[r].release(); rcount[r].release(); rcand[r].release(); }
             if (stream) (void)hipStreamDestroy(stream);
@@ -159,6 +160,7 @@ struct sr_scene {
 
 namespace {
 
+const int kMaxShaftSamples = 1024;       // area-light samples the shaft path takes (in chunks of 128); more: one lane per hit point (k_shadow)
 const int kMaxTreeDepth = 62;            // (depth + 2) stack levels x 256 lanes x 4 B = 64 KB of LDS per workgroup
 
 int use_device(sr_scene* s) {
@@ -488,7 +490,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     // (2) a REF_TREE frame whose caller does not read the traversal counters: the shadow rays only answer "is there a hit with
     //     rayFrac <= 1.0", which the own BVH answers identically (include/softray.h SR_MODE_BVH) -- they take the shaft path
     const bool shadows_on_bvh = (fc.flags & SR_F_SHADOWS) && f->trace_mode == SR_MODE_REF_TREE && !d_stats && s->bvh.built && !static_shadows &&
-                                (fc.flags & SR_F_POINT_LIGHT) && fc.shadow_samples <= 128 && f->max_bounces == 0 &&
+                                (fc.flags & SR_F_POINT_LIGHT) && fc.shadow_samples <= kMaxShaftSamples && f->max_bounces == 0 &&
                                 !(f->flags & (SR_F_SINGLE_KERNEL | SR_F_PER_LANE_SHADOWS)) && s->dbg[SR_DBG_LITERAL_SHADOWS] <= 0;
     if (shadows_on_bvh && (rc = sync_geometry(s, SR_MODE_BVH))) return rc;
     const bool bvh_walks = f->trace_mode == SR_MODE_BVH || shadows_on_bvh;
@@ -563,8 +565,10 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
     // ---- default: the primary / shadow / resolve pipeline, in row bands ----
     const long long n2 = (long long)fc.sub_pixel_res * fc.sub_pixel_res;
     const bool shadows = (fc.flags & SR_F_SHADOWS) != 0;
-    const bool shaft = shadows && bvh_walks && (fc.flags & SR_F_POINT_LIGHT) && fc.shadow_samples <= 128 &&
-                       !(f->flags & SR_F_PER_LANE_SHADOWS);
+    // (more than 128 samples: the shaft path runs in chunks of 128, escape counts summed per hit point; not for the static cache)
+    const bool shaft = shadows && bvh_walks && (fc.flags & SR_F_POINT_LIGHT) && !(f->flags & SR_F_PER_LANE_SHADOWS) &&
+                       (fc.shadow_samples <= 128 || (fc.shadow_samples <= kMaxShaftSamples && !static_shadows));
+    const bool chunked_shadows = shaft && fc.shadow_samples > 128;
     // samples per band: bounds the hit queue (64 B/sample) and, on the shaft path, the candidate lists (256 B/sample for
     // round 0 + 1/4 of the hits x 1 KB for round 1): 16 Mi samples = one 4096^2 frame = 10 GB of scratch in HBM
     long long kMaxBandSamples = shaft ? (16ll << 20) : (32ll << 20);
@@ -641,6 +645,15 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             }
         }
         if (n2 > 1) SR_HIP(B.samples.reserve((size_t)band_samples * 4));
+        bool accum_fresh = false;
+        if (chunked_shadows) {
+            // indexed like the sample buffer: the frame (or the compact strips) for one sample per pixel, band-local otherwise
+            const size_t idx_space = n2 == 1 ? (size_t)(f->strip_count > 0 ? fc.num_rows : fc.height) * fc.width : (size_t)band_samples;
+            if (idx_space * 4 > B.accum.cap || !B.accum.p) {
+                SR_HIP(B.accum.reserve(idx_space * 4));
+                accum_fresh = true;                                // zeroed on the half's own stream below
+            }
+        }
         SR_HIP(B.counters.reserve(64));
         hipStream_t bs = stream;
         if (split) {
@@ -652,6 +665,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         sr::PipelineLaunch P{};
         P.sc = dev_scene(s);
         P.fc = fc;
+        P.fc.accum = chunked_shadows ? (uint32_t*)B.accum.p : nullptr;
         P.mode = f->trace_mode;
         P.offsets = d_offsets;
         P.row_map = d_rowmap;
@@ -712,6 +726,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             if (hipEventRecord(e, st) != hipSuccess) { sc->collect_bands = false; return; }
             sc->band_recs.push_back({e, band, row_begin, row_count});
         };
+        if (accum_fresh) SR_HIP(hipMemsetAsync(B.accum.p, 0, B.accum.cap, bs));
         if (P.row_first < P.row_limit) SR_HIP(sr::launch_pipeline(P));
         if (split) {
             SR_HIP(hipEventRecord(B.done, bs));

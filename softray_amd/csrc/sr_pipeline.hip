@@ -38,8 +38,26 @@ __device__ __forceinline__ void finish_hit(const DevScene& sc, const FrameConst&
     if (fc.flags & 32u) {
         uint32_t v = (uint32_t)(int)(frac * 254 + 1) & 0xffu;
         sc.shadow_cache[cell] = (uint8_t)(v ? v : 1u);
+    } else if (fc.accum) {
+        // one chunk of a > 128-sample frame: frac = escapes / samples of THIS chunk, both <= 128, so the count comes back exactly
+        fc.accum[sample] += (uint32_t)(frac * (double)fc.shadow_samples + 0.5);
     } else {
         samples[sample] = modulate(shaded, to_byte(frac * 255));
+    }
+}
+
+// the last step of a chunked (> 128 samples) shadow stage: rayEscapeCount summed over the chunks -> (byte)(count / total * 255)
+// (ShadowMethod.cs:113-119) for every hit point of the band's queue; the sums are cleared for the next frame
+__global__ __launch_bounds__(256) void k_accum_finish(FrameConst fc, const HitRec* __restrict__ hits, const unsigned int* __restrict__ count,
+                                                      uint32_t* __restrict__ samples, int total_samples) {
+    const unsigned int total = *count, stride = gridDim.x * 256u;
+    for (unsigned int h = blockIdx.x * 256u + threadIdx.x; h < total; h += stride) {
+        const uint32_t sample = hits[h].sample;
+        if (sample == kInvalidHit) continue;
+        const uint32_t esc = fc.accum[sample];
+        fc.accum[sample] = 0u;
+        const double frac = (double)esc / (double)total_samples;
+        samples[sample] = modulate(samples[sample], to_byte(frac * 255));
     }
 }
 
@@ -1741,6 +1759,7 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
             const int esc = (int)__popcll(__ballot(escaped[0])) + (int)__popcll(__ballot(escaped[1]));
             if (lane == 0) {                                               // finish_hit with the tabulated byte
                 if (fc.flags & 32u) sc.shadow_cache[rec_cell] = (uint8_t)light_byte[esc];
+                else if (fc.accum) fc.accum[rec_sample] += (uint32_t)esc;      // (one chunk of a > 128-sample frame)
                 else samples[rec_sample] = modulate(shaded, light_byte[esc]);
             }
         }
@@ -2563,7 +2582,7 @@ static void pipe_events(const PipelineLaunch& L, int kid, hipEvent_t& e0, hipEve
 
 template <int MODE>
 static bool shaft_path(const PipelineLaunch& L) {
-    return MODE == MODE_BVH && (L.fc.flags & 8u) && L.fc.shadow_samples <= 64 * kPacketSlots && !L.per_lane_shadows && L.round_cand[0];
+    return MODE == MODE_BVH && (L.fc.flags & 8u) && (L.fc.shadow_samples <= 64 * kPacketSlots || L.fc.accum) && !L.per_lane_shadows && L.round_cand[0];
 }
 
 // counters: [0] hit_count  [1] k_shadow work head  [2] fallback_count  [3] fallback work head
@@ -2787,10 +2806,27 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
             T.tile_queue_n2 = pad_tiles ? n2 : 0;
             T.tile_queue_rows = row_count;
             const long long max_hits = (long long)((row_count + 15) / 16 * 16) * ((L.fc.width + 15) / 16 * 16) * n2;
-            // primary rays through the reference tree / brute force, shadow rays on the own BVH (sr_api.cpp decides when that is allowed)
-            if (MODE != MODE_BVH && L.shadows_on_bvh) e = launch_shadow_t<MODE_BVH, EXTRA>(T, samples, max_hits);
-            else e = launch_shadow_t<MODE, EXTRA>(T, samples, max_hits);
-            if (e != hipSuccess) return e;
+            // > 128 samples on the shaft path: one pass of the whole shadow stage per chunk of <= 128 samples, escape counts summed per
+            // hit point (FrameConst.accum), then k_accum_finish.  (The walk does not depend on the samples; repeating it keeps the rounds'
+            // bookkeeping -- undecided masks are 128 bits -- untouched.  The reference's count is the constant 100: ShadowMethod.cs:9.)
+            const int S = L.fc.shadow_samples, chunks = (shaft_frame && L.fc.accum && S > 64 * kPacketSlots) ? (S + 64 * kPacketSlots - 1) / (64 * kPacketSlots) : 1;
+            if (chunks == 1) T.fc.accum = nullptr;
+            for (int c = 0; c < chunks; ++c) {
+                if (chunks > 1) {
+                    T.fc.shadow_samples = std::min(64 * kPacketSlots, S - c * 64 * kPacketSlots);
+                    T.offsets = L.offsets + (size_t)c * 64 * kPacketSlots * 3;
+                    if (c > 0 && (e = hipMemsetAsync(L.counters + 1, 0, 15 * sizeof(unsigned int), L.stream)) != hipSuccess) return e;
+                }
+                // primary rays through the reference tree / brute force, shadow rays on the own BVH (sr_api.cpp decides when that is allowed)
+                if (MODE != MODE_BVH && L.shadows_on_bvh) e = launch_shadow_t<MODE_BVH, EXTRA>(T, samples, max_hits);
+                else e = launch_shadow_t<MODE, EXTRA>(T, samples, max_hits);
+                if (e != hipSuccess) return e;
+            }
+            if (chunks > 1) {
+                const unsigned blocks = (unsigned)std::min<long long>((max_hits + 255) / 256, (long long)L.persistent_blocks);
+                hipLaunchKernelGGL(k_accum_finish, dim3(blocks), dim3(256), 0, L.stream, T.fc, (const HitRec*)L.hits, L.counters, samples, S);
+                if ((e = hipGetLastError()) != hipSuccess) return e;
+            }
         }
         if (n2 > 1) {
             e0 = e1 = nullptr;

@@ -130,6 +130,10 @@ struct FrameConst {
     int32_t  max_bounces;        // config-5 extension: mirror bounces (0 = the reference's behaviour)
     double   reflectivity;
     double   light_radius;       // max |area-light offset| (0.2 for the reference table): bounds the shadow shaft
+    // More than 128 samples on the shaft path: the shadow stage runs once per chunk of <= 128 samples (shadow_samples = the chunk's count)
+    // and ADDS every hit point's escape count to accum[sample index] instead of finishing the pixel; k_accum_finish turns the sums
+    // into ShadowMethod's byte with the total count.  nullptr: the ordinary one-pass frame.
+    uint32_t* accum;
 };
 
 }  // namespace sr

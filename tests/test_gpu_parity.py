@@ -304,10 +304,11 @@ def test_error_codes_on_gpu(obj_pair):
 
 def test_shadow_sample_variants(obj_pair):
     """ShadowMethod with other sample tables: 1 sample / zero offset (hard-shadow variant), odd counts, a caller-supplied
-    offset table (what the C# shim passes), and > 128 samples (per-lane kernel instead of the shaft path)."""
+    offset table (what the C# shim passes), and > 128 samples (the shaft path in chunks of 128, escape counts summed per hit point:
+    130 = 128 + 2, 200, 300 = three chunks; render_both adds the one-kernel and the per-lane schedule as cross-checks)."""
     g, o = obj_pair
     rnd = orc.Random(4242)
-    for count in (1, 7, 64, 65, 100, 128, 130):
+    for count in (1, 7, 64, 65, 100, 128, 130, 200, 300):
         f = make_frame(72, 56, shadows=True, shadow_samples=count)
         if count == 1:
             table = np.zeros((1, 3))
@@ -322,6 +323,11 @@ def test_shadow_sample_variants(obj_pair):
         for mode in (sa.MODE_BVH, sa.MODE_REF_TREE):
             got, _ = render_both(g, f, mode)
             assert np.array_equal(got, want), (count, mode)
+        if count > 128:                                   # sub-pixel sampling (band-local sample indices), twice (the sums must be cleared)
+            f2 = make_frame(72, 56, shadows=True, shadow_samples=count, sub_pixel_res=2)
+            want2, _ = o.render(f2, threads=NCPU)
+            for _ in range(2):
+                assert np.array_equal(g.render(as_sr(f2, sa.MODE_BVH), stats=False)[0], want2), count
 
 
 def test_shadow_method_shortcuts_change_no_pixel(obj_pair):
