@@ -346,13 +346,32 @@ struct SampleRay {
     double offset;      // rayFracOffset (:401)
 };
 
-__device__ __forceinline__ bool prepare_sample(const DevScene& sc, D3 rs, D3 rd, SampleRay& r) {
+__device__ __forceinline__ bool prepare_sample(const RootBox& root, D3 rs, D3 rd, SampleRay& r) {
     D3 end = rs + rd * 10000.0;
     r.s = rs;
     r.d = rd;
-    if (!clip_segment<false>(sc.root, r.s, end)) return false;
+    if (!clip_segment<false>(root, r.s, end)) return false;
     r.offset = length(rs - r.s) / length(rd);
     return true;
+}
+
+__device__ __forceinline__ bool prepare_sample(const DevScene& sc, D3 rs, D3 rd, SampleRay& r) { return prepare_sample(sc.root, rs, rd, r); }
+
+// A kernel argument read WHERE IT IS NEEDED, from the kernel-argument segment (byte offset `offset`), through a pointer the
+// compiler cannot see through: it loads every argument it can name at the top of the kernel and keeps it in scalar registers
+// for good -- the root box alone is 48 of them, which a rare FP64 path needs and the loop around it then pays for with
+// v_readlane / v_writelane spills.
+template <typename T>
+__device__ __forceinline__ T kernarg_late(size_t offset) {
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "whole 32-bit words");
+    typedef const uint32_t __attribute__((address_space(4))) CW4;
+    CW4* kp = (CW4*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    T out;
+    uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) o[i] = kp[offset / 4 + i];
+    return out;
 }
 
 template <bool EXTRA>
@@ -1396,6 +1415,9 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                                                     unsigned int* __restrict__ last_count, unsigned int* __restrict__ last_list,
                                                     RoundState* __restrict__ last_state,
                                                     uint32_t* __restrict__ samples, unsigned long long* stats) {
+    // (the first round -- no tail layout -- is the one launched without saved masks and with lists stored per hit: compile-time facts)
+    if (!TAIL) { state_in = nullptr; lists_by_hit = 1; }
+    else lists_by_hit = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     float4* wc = reinterpret_cast<float4*>(lds_pipe) + (size_t)wave * kClsWaveF4;   // per-candidate records (owner layout)
@@ -1721,13 +1743,14 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                         const int sj = lane + 64 * q;
                         const D3 rs = lpos + mk(offsets[3 * sj], offsets[3 * sj + 1], offsets[3 * sj + 2]);
                         SampleRay ray;
-                        bool is_alive = prepare_sample(sc, rs, E - rs, ray);  // false: the ray misses the root box, nothing can block it
+                        const RootBox root = kernarg_late<RootBox>(offsetof(DevScene, root));   // (the scene is the kernel's first argument)
+                        bool is_alive = prepare_sample(root, rs, E - rs, ray);  // false: the ray misses the root box, nothing can block it
                         bool blocked = false;
                         while (is_alive && m) {
                             const int k = __ffs((int)m) - 1;
                             m &= m - 1u;
                             if (STATS) n_exact++;
-                            if (tri_blocks(sc.btris[wrecidx[k]].p, ray, sc.root.lo, sc.root.hi)) { is_alive = false; blocked = true; }
+                            if (tri_blocks(sc.btris[wrecidx[k]].p, ray, root.lo, root.hi)) { is_alive = false; blocked = true; }
                         }
                         if (!is_alive) {
                             if (q) { alive[1] = false; if (blocked) escaped[1] = false; }
