@@ -320,7 +320,9 @@ enum {
     SR_DBG_BVH_LEAF       = 5,   /* triangles per leaf of the own BVH, host and device build (default 4, 1..15); read by the next sr_build */
     SR_DBG_KERNEL_SWITCH  = 6,   /* A/B switch of single optimisations, same pixels (0 = production): 31 the bounce pipeline walks its rays in
                                     queue order (no per-level ray sort); 61 the camera-ordered node copy keeps (lo, hi) planes; 71 no facing
-                                    partition (the packet walks see every record of a leaf); 7 counts umbra decisions of the private shaft walk */
+                                    partition (the packet walks see every record of a leaf); 7 counts umbra decisions of the private shaft walk;
+                                    32 a mirror-bounce level as ONE kernel (k_bounce) instead of prepare / walk / finish; 100 + T: the walk kernel
+                                    fetches new rays at T busy lanes (default 24); 200 + K: K stack levels per lane in LDS (default 24)     */
     SR_DBG_KERNEL_TIMING  = 7,   /* > 0: record a HIP event pair around every launch (sr_kernel_times); default off           */
     SR_DBG_EXACT_SHADOW_TESTS = 8, /* > 0: k_shadow_test decides every (sample, triangle) pair with the FP64 arithmetic (no
                                     fp32 classification): an independent schedule of the same result, kept as a cross-check */

@@ -118,14 +118,14 @@ struct sr_scene {
     // the short, latency-bound tail kernels of one half (second shaft round, fallback walks) overlap the other half's work
     static constexpr int kMaxSplit = 4;
     struct BandScratch {
-        DBuf hits, hits2, bounce_levels, bounce_nlev, samples, counters, fallback, fallback_state, fallback_rays, fallback_ovf, ray_sort, ray_sort_temp;
+        DBuf hits, hits2, bounce_levels, bounce_nlev, bounce_prep, bounce_res, bounce_stack, samples, counters, fallback, fallback_state, fallback_rays, fallback_ovf, ray_sort, ray_sort_temp;
         DBuf accum;                        // escape counts per sample index of a chunked (> 128 samples) shadow stage; zero between frames
         DBuf rlist[sr::kShaftRounds], rstate[sr::kShaftRounds], rcount[sr::kShaftRounds], rcand[sr::kShaftRounds];
         hipStream_t stream = nullptr;
         hipEvent_t  done = nullptr;
         bool used_last_frame = false;
         void release() {
-            DBuf* b[] = {&hits, &hits2, &bounce_levels, &bounce_nlev, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf, &ray_sort, &ray_sort_temp, &accum};
+            DBuf* b[] = {&hits, &hits2, &bounce_levels, &bounce_nlev, &bounce_prep, &bounce_res, &bounce_stack, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf, &ray_sort, &ray_sort_temp, &accum};
             for (DBuf* x : b) x->release();
             for (int r = 0; r < sr::kShaftRounds; ++r) { rlist[r].release(); rstate[r].release(); rcount[r].release(); rcand[r].release(); }
             if (stream) (void)hipStreamDestroy(stream);
@@ -628,6 +628,11 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             SR_HIP(B.hits2.reserve((size_t)band_samples * sr::pipeline_hit_record_bytes()));
             SR_HIP(B.bounce_levels.reserve(idx_space * (size_t)(f->max_bounces + 1) * 4));
             SR_HIP(B.bounce_nlev.reserve(idx_space));
+            SR_HIP(B.bounce_prep.reserve((size_t)band_samples * 64));
+            SR_HIP(B.bounce_res.reserve((size_t)band_samples * 16));
+            // (k_bounce_walk keeps sr::pipeline_bounce_lds_levels() stack levels per lane in LDS, the rest of the worst case here)
+            const long long deep = std::max(3 * (long long)s->b4_depth + 2, (long long)s->bvh.depth + 2) - sr::pipeline_bounce_lds_levels();
+            if (deep > 0) SR_HIP(B.bounce_stack.reserve((size_t)deep * (size_t)s->num_cus * 8 * 256 * 4));
             // per-level ray order (keys, sorted keys, indices, order) + the device sort's own scratch
             SR_HIP(B.ray_sort.reserve((size_t)band_samples * 4 * 4));
             SR_HIP(B.ray_sort_temp.reserve(sr::ray_sort_temp_bytes((unsigned)band_samples)));
@@ -678,6 +683,10 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.ray_sort_temp_bytes = bounce_pipe ? sr::ray_sort_temp_bytes((unsigned)band_samples) : 0;
         P.bounce_levels = bounce_pipe ? (uint32_t*)B.bounce_levels.p : nullptr;
         P.bounce_nlev = bounce_pipe ? (uint8_t*)B.bounce_nlev.p : nullptr;
+        P.bounce_prep = bounce_pipe ? B.bounce_prep.p : nullptr;
+        P.bounce_res = bounce_pipe ? B.bounce_res.p : nullptr;
+        P.bounce_stack = bounce_pipe ? (int32_t*)B.bounce_stack.p : nullptr;
+        P.bounce_stack_bytes = bounce_pipe ? B.bounce_stack.cap : 0;
         P.counters = (unsigned int*)B.counters.p;
         P.static_hits = static_shadows ? s->d_static_hits.p : nullptr;
         P.static_claim = static_shadows ? (unsigned long long*)s->d_static_claim.p : nullptr;

@@ -81,6 +81,10 @@ struct PipelineLaunch {
     size_t        ray_sort_temp_bytes;
     uint32_t*     bounce_levels; // device [band samples][max_bounces + 1]: colour of every level of a sample's mirror chain
     uint8_t*      bounce_nlev;  // device [band samples]: levels stored | 0x80 when the deepest level is a surface
+    void*         bounce_prep;  // device [band samples] x 64 B: a level's rays after the FP64 clip, in walk order (k_bounce_prep)
+    void*         bounce_res;   // device [band samples] x 16 B: nearest hit of every such ray (k_bounce_walk)
+    int32_t*      bounce_stack; // device: the part of k_bounce_walk's per-lane stacks that does not live in LDS ([level][lane])
+    size_t        bounce_stack_bytes;
     void*         static_hits;  // device HitRec[min(band samples, 128^3)]: generators of a static-shadow frame
     unsigned long long* static_claim; // device [128^3]: smallest order key that asked for an empty cell
     int32_t       static_concurrency; // rayTraceConcurrency of the frame
@@ -126,6 +130,7 @@ size_t pipeline_hit_record_bytes();
 size_t pipeline_static_cells();
 int pipeline_round_cap(int round);
 int pipeline_round_cap_max(int round);
+int pipeline_bounce_lds_levels();      // stack levels per lane k_bounce_walk keeps in LDS (deeper ones live in PipelineLaunch::bounce_stack)
 size_t pipeline_round_state_bytes();
 
 // Own BVH built on the device (sr_lbvh.hip).  Inputs in TriangleIndex order, outputs caller-allocated (n entries each).

@@ -2297,6 +2297,282 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
     }
 }
 
+// --------------------------------------------------------------------------------------------------
+// The same level as THREE kernels (default; k_bounce above stays as the one-kernel form, SR_DBG_KERNEL_SWITCH 32): what a ray needs before
+// its walk (FP64 clip against the root box, rayFracOffset) and after it (shading with its pow(), level colour, next reflection,
+// queue append) is work for a full wave over consecutive rays; inside the walk kernel it ran at the refill points for the lanes
+// that happened to have finished, and -- being expensive -- forced few, late refills (8 of 64 lanes still walking).  Split off,
+//   k_bounce_prep    lane = ray (walk order): clip, offset -> 64-byte BounceRay
+//   k_bounce_walk    persistent lanes: a refill is one 64-byte load + the fp32 frames, so it happens at kWalkRefillAt busy lanes;
+//                    the walk itself is k_bounce's, a finished lane stores (t, record) and waits for the next refill
+//   k_bounce_finish  lane = ray: k_bounce's finishing block
+// Same per-ray arithmetic in the same order, same results.
+// --------------------------------------------------------------------------------------------------
+struct alignas(16) BounceRay {
+    double   s[3], d[3];         // clipped start (SpatialSubdivision.cs:394), direction as queued
+    double   offset;             // rayFracOffset (:401); < 0: the ray misses the root box, no walk
+    uint32_t sample, level;
+};
+static_assert(sizeof(BounceRay) == 64, "BounceRay must be 64 bytes");
+struct alignas(16) BounceHit {
+    double  best;                // rayFrac from the clipped start of the nearest triangle hit (DBL_MAX: none)
+    int32_t bestK, pad;          // its record (-1: none)
+};
+static_assert(sizeof(BounceHit) == 16, "BounceHit must be 16 bytes");
+constexpr int kWalkRefillAt = 24;        // k_bounce_walk fetches new rays when at most this many lanes are still walking (8: 43.4 ms, 24: 43.3, 32: 43.9, 48: 45.3, 62: 47.5 at C5)
+// The worst case of a lane's stack is 3 * depth + 2 entries -- 60 KB of LDS per workgroup at C5, i.e. two workgroups per CU, and an
+// incoherent walk lives on the number of waves that wait side by side.  Only the first kBounceLdsLevels live in LDS; the deeper
+// ones (rare) in global memory, [level][lane].
+constexpr int kBounceLdsLevels = 24;     // C5, four bounces: all 59 levels in LDS 44.1 ms, 32: 41.1, 24: 41.0, 16: 44.1, 12: 44.1
+struct SplitStack {
+    int32_t* lds;        // &lds[threadIdx], stride 256
+    int32_t* deep;       // &deep[global lane], stride = lanes of the grid
+    int32_t  lds_levels, deep_stride;
+    __device__ __forceinline__ void put(int level, int32_t v) {
+        if (level < lds_levels) lds[level * 256] = v; else deep[(size_t)(level - lds_levels) * (size_t)deep_stride] = v;
+    }
+    __device__ __forceinline__ int32_t get(int level) const {
+        return level < lds_levels ? lds[level * 256] : deep[(size_t)(level - lds_levels) * (size_t)deep_stride];
+    }
+};
+
+__global__ __launch_bounds__(256) void k_bounce_prep(DevScene sc, const HitRec* __restrict__ qin, const unsigned int* __restrict__ qin_count,
+                                                     const unsigned int* __restrict__ order, BounceRay* __restrict__ prep, BounceHit* __restrict__ res) {
+    const unsigned int total = *qin_count, stride = gridDim.x * 256u;
+    for (unsigned int r = blockIdx.x * 256u + threadIdx.x; r < total; r += stride) {
+        const HitRec q = qin[order ? order[r] : r];                            // (sr_raysort.hip: rays of a cell and octant side by side)
+        const D3 s0 = mk(q.pos[0], q.pos[1], q.pos[2]), d = mk(q.nrm[0], q.nrm[1], q.nrm[2]);
+        D3 s = s0;
+        D3 end = s + d * 10000.0;
+        const bool walking = clip_segment<false>(sc.root, s, end);
+        BounceRay o;
+        o.s[0] = s.x; o.s[1] = s.y; o.s[2] = s.z;
+        o.d[0] = d.x; o.d[1] = d.y; o.d[2] = d.z;
+        o.offset = walking ? length(s0 - s) / length(d) : -1.0;
+        o.sample = q.sample; o.level = q.pad[0];
+        prep[r] = o;
+        BounceHit h;
+        h.best = DBL_MAX; h.bestK = -1; h.pad = 0;
+        res[r] = h;
+    }
+}
+
+// (119 VGPRs = 4 waves/SIMD; forced to 96 for 5 it spills: 46.2 instead of 41.0 ms at C5)
+template <bool STATS, bool WIDE>
+__global__ __launch_bounds__(256) void k_bounce_walk(DevScene sc, const BounceRay* __restrict__ prep, const unsigned int* __restrict__ count,
+                                                     unsigned int* __restrict__ head, BounceHit* __restrict__ res, unsigned long long* stats, int refill_at,
+                                                     int32_t* __restrict__ deep, int lds_levels) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    SplitStack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, deep + (size_t)blockIdx.x * 256u + (unsigned)tid, lds_levels, (int32_t)(gridDim.x * 256u)};
+    const unsigned int total = *count;
+    const float kInfl = 1.0f + 9.5367431640625e-7f;          // 1 + 2^-20
+    Ctr sec = {0, 0, 0, 0};
+    // ---- per ray ----
+    unsigned int mine = 0;                     // position of the lane's ray in prep / res
+    D3 s = mk(0, 0, 0), d = mk(0, 0, 0);
+    double best = DBL_MAX;
+    int32_t bestIdx = 0x7fffffff, bestK = -1;
+    f2 I01 = splat(0.0f), I20 = I01, I12 = I01, B0 = I01, B1 = I01, B2 = I01;
+    RayF rf = {};
+    float tlim = FLT_MAX;
+    int sp = 0;
+    int32_t ni = -1, leafA = -1, leafB = -1, leafC = -1, leafD = -1, leafE = -1, leafF = -1, leafG = -1, leafH = -1;
+    bool active = false;
+    bool drained = false;
+    for (;;) {
+        const unsigned long long busy = __ballot(active);
+        if (!drained && (int)__popcll(busy) <= refill_at) {
+            const unsigned long long m = ~busy;
+            unsigned int base = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) base = atomicAdd(head, (unsigned int)__popcll(m));
+            base = __shfl(base, leader, 64);
+            drained = base + (unsigned int)__popcll(m) >= total;
+            if (!active) {
+                const unsigned int r = base + (unsigned int)__popcll(m & lanemask_lt());
+                if (r < total) {
+                    const BounceRay q = prep[r];
+                    if (q.offset >= 0.0) {
+                        mine = r;
+                        s = mk(q.s[0], q.s[1], q.s[2]);
+                        d = mk(q.d[0], q.d[1], q.d[2]);
+                        sec.rays++;
+                        best = DBL_MAX; bestIdx = 0x7fffffff; bestK = -1;
+                        const float ox = (float)(s.x - sc.root.centre[0]), oy = (float)(s.y - sc.root.centre[1]), oz = (float)(s.z - sc.root.centre[2]);
+                        const float ix = slab_inv((float)d.x), iy = slab_inv((float)d.y), iz = slab_inv((float)d.z);
+                        I01 = (f2){ix, iy}; I20 = (f2){iz, ix}; I12 = (f2){iy, iz};
+                        B0 = (f2){-ox * ix, -oy * iy}; B1 = (f2){-oz * iz, -ox * ix}; B2 = (f2){-oy * iy, -oz * iz};
+                        tlim = FLT_MAX;
+                        rf = make_ray_f(sc, s, d);
+                        sp = 0; ni = 0; leafA = -1; leafB = -1; leafC = -1; leafD = -1; leafE = leafF = leafG = leafH = -1;
+                        active = true;
+                    } else if (STATS) sec.rays++;
+                }
+            }
+        }
+        if (!__any(active)) {
+            if (drained) break;
+            continue;
+        }
+        if (active) {
+            // (the speculative walk of k_bounce: up to eight pending leaves, on while at most four wait)
+            while (WIDE && ni >= 0 && leafE < 0) {
+                const Bvh4Node n = sc.b4[ni];
+                sec.nodes++;
+                float tk[4];
+                int32_t ck[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float t, x;
+                    child_slabs(n.ch[k], I01, I20, I12, B0, B1, B2, t, x);
+                    const bool h = n.ch[k].n >= 0 && t <= x && x >= 0.0f && t <= tlim;
+                    tk[k] = (h && n.ch[k].n == 0) ? t : FLT_MAX;
+                    ck[k] = n.ch[k].c;
+                    if (h && n.ch[k].n > 0) {
+                        const int32_t v = n.ch[k].c | (n.ch[k].n << kLeafShift);
+                        if (leafA < 0) leafA = v; else if (leafB < 0) leafB = v; else if (leafC < 0) leafC = v; else if (leafD < 0) leafD = v; else if (leafE < 0) leafE = v; else if (leafF < 0) leafF = v; else if (leafG < 0) leafG = v; else leafH = v;
+                    }
+                }
+#define SR_CE(a, b) { const bool sw = tk[b] < tk[a]; const float ta = tk[a]; const int32_t ca = ck[a]; \
+                      tk[a] = sw ? tk[b] : ta; ck[a] = sw ? ck[b] : ca; tk[b] = sw ? ta : tk[b]; ck[b] = sw ? ca : ck[b]; }
+                SR_CE(0, 1) SR_CE(2, 3) SR_CE(0, 2) SR_CE(1, 3) SR_CE(1, 2)
+#undef SR_CE
+                if (tk[3] < FLT_MAX) st.put(sp++, ck[3]);
+                if (tk[2] < FLT_MAX) st.put(sp++, ck[2]);
+                if (tk[1] < FLT_MAX) st.put(sp++, ck[1]);
+                ni = tk[0] < FLT_MAX ? ck[0] : ((sp > 0) ? st.get(--sp) : -1);
+            }
+            while (!WIDE && ni >= 0 && leafA < 0) {
+                const BvhNode n = sc.bnodes[ni];
+                sec.nodes++;
+                float t0, x0, t1, x1;
+                node_slabs(n, I01, I20, I12, B0, B1, B2, t0, x0, t1, x1);
+                const bool h0 = n.n0 >= 0 && t0 <= x0 && x0 >= 0.0f && t0 <= tlim;
+                const bool h1 = n.n1 >= 0 && t1 <= x1 && x1 >= 0.0f && t1 <= tlim;
+                const bool l0 = h0 && n.n0 > 0, l1 = h1 && n.n1 > 0;
+                if (l0 && l1) {
+                    const bool first0 = t0 <= t1;
+                    leafA = (first0 ? n.c0 : n.c1) | ((first0 ? n.n0 : n.n1) << kLeafShift);
+                    leafB = (first0 ? n.c1 : n.c0) | ((first0 ? n.n1 : n.n0) << kLeafShift);
+                } else if (l0) leafA = n.c0 | (n.n0 << kLeafShift);
+                else if (l1) leafA = n.c1 | (n.n1 << kLeafShift);
+                const bool i0 = h0 && n.n0 == 0, i1 = h1 && n.n1 == 0;
+                if (i0 && i1) {
+                    const bool first0 = t0 <= t1;
+                    st.put(sp++, first0 ? n.c1 : n.c0);
+                    ni = first0 ? n.c0 : n.c1;
+                } else if (i0) ni = n.c0;
+                else if (i1) ni = n.c1;
+                else ni = (sp > 0) ? st.get(--sp) : -1;
+            }
+            while (leafA >= 0) {
+                const int32_t first = leafA & kLeafMask, cn = (leafA >> kLeafShift) & 15;
+                leafA = leafB;
+                leafB = WIDE ? leafC : -1;
+                if (WIDE) { leafC = leafD; leafD = leafE; leafE = leafF; leafF = leafG; leafG = leafH; leafH = -1; }
+                sec.leaves++;
+                for (uint32_t m = leaf_survivors(sc, first, cn, rf, tlim); m; m &= m - 1u) {
+                    const int k = first + (__ffs((int)m) - 1);
+                    const Rec128* r = &sc.btris[k];
+                    double t; D3 pos;
+                    sec.geom++;
+                    if (tri_hit(r->p, s, d, t, pos) && inside(sc.root.lo, sc.root.hi, pos)) {
+                        const int32_t idx = r->aux;
+                        if (t < best || (t == best && idx < bestIdx)) {
+                            best = t; bestIdx = idx; bestK = k;
+                            tlim = (float)best * kInfl + 1e-30f;
+                        }
+                    }
+                }
+            }
+            if (ni < 0 && leafA < 0) {                            // the walk is over
+                BounceHit h;
+                h.best = best; h.bestK = bestK; h.pad = 0;
+                res[mine] = h;
+                active = false;
+            }
+        }
+    }
+    if (STATS) {
+        uint32_t a = wave_sum(sec.rays), b = wave_sum(sec.geom), c2 = wave_sum(sec.nodes), d2 = wave_sum(sec.leaves);
+        if (lane == 0) {
+            stat_add(&stats[4], a); stat_add(&stats[5], b); stat_add(&stats[6], c2); stat_add(&stats[7], d2);
+            stat_add(&stats[20], a); stat_add(&stats[21], b); stat_add(&stats[22], c2); stat_add(&stats[23], d2);   // mirror rays on their own
+        }
+    }
+}
+
+template <bool EXTRA, bool STATS>
+__global__ __launch_bounds__(256) void k_bounce_finish(DevScene sc, FrameConst fc, const HitRec* __restrict__ qin, const unsigned int* __restrict__ qin_count,
+                                                       const unsigned int* __restrict__ order, const BounceRay* __restrict__ prep,
+                                                       const BounceHit* __restrict__ res, HitRec* __restrict__ qout, unsigned int* __restrict__ qout_count,
+                                                       uint32_t* __restrict__ levels, uint8_t* __restrict__ nlev, unsigned long long* stats) {
+    const unsigned int total = *qin_count, stride = gridDim.x * 256u;
+    const int maxb = fc.max_bounces;
+    uint32_t n_geom = 0;
+    for (unsigned int r0 = blockIdx.x * 256u; r0 < total; r0 += stride) {          // whole waves stay in the loop (the queue append is wave-aggregated)
+        const unsigned int r = r0 + threadIdx.x;
+        if (r >= total) continue;
+        const BounceRay p = prep[r];
+        const BounceHit h = res[r];
+        const D3 s = mk(p.s[0], p.s[1], p.s[2]), d = mk(p.d[0], p.d[1], p.d[2]);
+        const bool walking = p.offset >= 0.0;
+        const uint32_t sample = p.sample, level = p.level;
+        double ex_t = DBL_MAX;                     // nearest extra-geometry hit (GeometryCollection order, strict '<'), from the UNCLIPPED start
+        D3 ex_pos = mk(0, 0, 0), ex_nrm = mk(0, 0, 0);
+        uint32_t ex_color = 0;
+        if (EXTRA) {
+            const HitRec q = qin[order ? order[r] : r];
+            const D3 s0 = mk(q.pos[0], q.pos[1], q.pos[2]);
+            for (int i = 0; i < sc.nextra; ++i) {
+                const Rec128* e = &sc.extra[i];
+                double t; D3 pos, nrm;
+                bool ok;
+                const int kind = e->aux;
+                if (kind == 0) ok = sphere_hit(e->p, s0, d, t, pos, nrm);
+                else if (kind == 1) { ok = plane_hit(e->p, s0, d, t, pos); nrm = mk(e->p[0], e->p[1], e->p[2]); }
+                else { ok = tri_hit(e->p, s0, d, t, pos); nrm = mk(e->p[0], e->p[1], e->p[2]); }
+                n_geom++;
+                if (ok && t < ex_t) { ex_t = t; ex_pos = pos; ex_nrm = nrm; ex_color = e->color; }
+            }
+        }
+        bool hit = false;
+        D3 hpos = ex_pos, hnrm = ex_nrm;
+        uint32_t hcol = ex_color;
+        if (ex_t < DBL_MAX) hit = true;
+        if (walking && h.bestK >= 0 && (h.best + p.offset) < ex_t) {
+            const Rec128* t = &sc.btris[h.bestK];
+            hit = true;
+            hpos = s + d * h.best;
+            hnrm = mk(t->p[0], t->p[1], t->p[2]);
+            hcol = t->color;
+        }
+        if (hit) {
+            uint32_t color = hcol;
+            if (fc.flags & 1u) color = shade(fc, hpos, hnrm, color);
+            levels[(size_t)sample * (size_t)(maxb + 1) + level] = color;
+            const uint32_t nl = level + 1u;
+            if ((int)nl > maxb) {
+                nlev[sample] = (uint8_t)(nl | 0x80u);                  // the deepest level is a surface: nothing beyond it
+            } else {
+                nlev[sample] = (uint8_t)nl;
+                HitRec o;
+                const D3 refl = d - hnrm * (2.0 * dot(d, hnrm));
+                const D3 org = hpos + hnrm * 0.001;
+                o.pos[0] = org.x; o.pos[1] = org.y; o.pos[2] = org.z;
+                o.nrm[0] = refl.x; o.nrm[1] = refl.y; o.nrm[2] = refl.z;
+                o.sample = sample;
+                o.pad[0] = nl; o.pad[1] = o.pad[2] = 0;
+                qout[atomicAdd(qout_count, 1u)] = o;                   // the compiler aggregates this per wavefront
+            }
+        }
+    }
+    if (STATS && EXTRA) {
+        const uint32_t b = wave_sum(n_geom);
+        if ((threadIdx.x & 63) == 0) { stat_add(&stats[5], b); stat_add(&stats[21], b); }
+    }
+}
+
 // blend the stored levels of every sample back to front (the fold of trace_camera_ray)
 __global__ __launch_bounds__(256) void k_fold(FrameConst fc, long long nsamples, const uint32_t* __restrict__ levels, const uint8_t* __restrict__ nlev,
                                               uint32_t* __restrict__ samples, const int32_t* __restrict__ row_map, int row_begin, int row_count) {
@@ -2789,11 +3065,33 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
                     if ((e = ray_sort(qin, L.counters + cur, cap, L.sc.root, b, b + (size_t)cap, b + 2 * (size_t)cap, b + 3 * (size_t)cap, L.ray_sort_temp, L.ray_sort_temp_bytes, L.stream)) != hipSuccess) return e;
                     order = b + 3 * (size_t)cap;
                 }
-                const auto go = [&](auto kern) {
-                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, qin, L.counters + cur, qout, L.counters + (1 - cur), L.counters + 2, L.bounce_levels, L.bounce_nlev, L.stats, order);
-                };
-                if (wide) { if (L.stats) go(k_bounce<EXTRA, true, true>); else go(k_bounce<EXTRA, false, true>); }
-                else { if (L.stats) go(k_bounce<EXTRA, true, false>); else go(k_bounce<EXTRA, false, false>); }
+                if (L.fc.debug == 32 || !L.bounce_prep || !L.bounce_res) {      // (hook: the level as one kernel)
+                    const auto go = [&](auto kern) {
+                        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, qin, L.counters + cur, qout, L.counters + (1 - cur), L.counters + 2, L.bounce_levels, L.bounce_nlev, L.stats, order);
+                    };
+                    if (wide) { if (L.stats) go(k_bounce<EXTRA, true, true>); else go(k_bounce<EXTRA, false, true>); }
+                    else { if (L.stats) go(k_bounce<EXTRA, true, false>); else go(k_bounce<EXTRA, false, false>); }
+                } else {
+                    BounceRay* prep = (BounceRay*)L.bounce_prep;
+                    BounceHit* res = (BounceHit*)L.bounce_res;
+                    hipLaunchKernelGGL(k_bounce_prep, dim3(blocks), dim3(256), 0, L.stream, L.sc, qin, L.counters + cur, order, prep, res);
+                    // stack levels in LDS: kBounceLdsLevels when the rest of the worst case fits the overflow buffer, all of them otherwise
+                    const int levels_all = (int)(lds / (256 * 4));
+                    int lds_levels = (L.fc.debug >= 200 && L.fc.debug < 300) ? L.fc.debug - 200 : kBounceLdsLevels;      // (hook)
+                    lds_levels = std::max(1, std::min(lds_levels, levels_all));
+                    if ((size_t)(levels_all - lds_levels) * (size_t)blocks * 256 * 4 > L.bounce_stack_bytes || !L.bounce_stack) lds_levels = levels_all;
+                    const auto walk = [&](auto kern) {
+                        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), (size_t)lds_levels * 256 * 4, L.stream, L.sc, (const BounceRay*)prep, L.counters + cur, L.counters + 2, res, L.stats,
+                                           (L.fc.debug >= 100 && L.fc.debug < 164) ? L.fc.debug - 100 : kWalkRefillAt, L.bounce_stack, lds_levels);
+                    };
+                    if (wide) { if (L.stats) walk(k_bounce_walk<true, true>); else walk(k_bounce_walk<false, true>); }
+                    else { if (L.stats) walk(k_bounce_walk<true, false>); else walk(k_bounce_walk<false, false>); }
+                    const auto fin = [&](auto kern) {
+                        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, L.stream, L.sc, L.fc, qin, L.counters + cur, order, (const BounceRay*)prep, (const BounceHit*)res,
+                                           qout, L.counters + (1 - cur), L.bounce_levels, L.bounce_nlev, L.stats);
+                    };
+                    if (L.stats) fin(k_bounce_finish<EXTRA, true>); else fin(k_bounce_finish<EXTRA, false>);
+                }
                 if ((e = hipGetLastError()) != hipSuccess) return e;
                 cur = 1 - cur;
             }
@@ -2883,6 +3181,7 @@ int pipeline_round_cap(int round) { return kRoundCap[round]; }   // default list
 // longest list the kernels handle (sr_debug_set hooks): 64 in the first round and wherever k_shadow_test keeps the list in the
 // registers of one wave; the later rounds of the default path (k_shaft_coop, k_shadow_cls) read and write it in chunks
 int pipeline_round_cap_max(int round) { return round == 0 ? 64 : 1024; }
+int pipeline_bounce_lds_levels() { return kBounceLdsLevels; }
 size_t pipeline_round_state_bytes() { return sizeof(RoundState); }
 
 }  // namespace sr

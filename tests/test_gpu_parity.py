@@ -763,6 +763,18 @@ def test_reflection_extension_matches_oracle():
     assert np.array_equal(single, want)
     nosplit = as_sr(f, sa.MODE_BVH); nosplit.flags |= sa._lib.F_NO_SPLIT
     assert np.array_equal(g.render(nosplit)[0], want)
+    # schedules of a level: one kernel instead of prepare / walk / finish (32); the walk with two stack levels per lane in LDS, the
+    # rest in global memory (202), refilled at 60 busy lanes (160) and only when the wave is empty (100); with ray statistics
+    ref_stats = None
+    for hook in (32, 202, 160, 100):
+        g.debug_set(sa._lib.DBG_KERNEL_SWITCH, hook)
+        try:
+            px, st_ = g.render(as_sr(f, sa.MODE_BVH))
+        finally:
+            g.debug_set(sa._lib.DBG_KERNEL_SWITCH, -1)
+        assert np.array_equal(px, want), hook
+        if ref_stats is None: ref_stats = st_[:8].copy()
+        assert np.array_equal(st_[:8], ref_stats), hook        # the same rays, the same walks: counters do not depend on the schedule
     g.debug_set(sa._lib.DBG_BAND_SAMPLES, 3000)
     try:
         assert np.array_equal(g.render(as_sr(f, sa.MODE_BVH))[0], want)
