@@ -545,7 +545,8 @@ def main():
             # incoherent rays, one per lane: 4 B ray id + 8 B mask RMW per shadow ray, 2 x 64 B queue records + 5 B level colour per mirror
             # ray; every LANE fetches its own 64 B nodes and 128 B FP64 records
             "k_shadow_fallback": rs[16] * 12.0 + rs[18] * S_NODE + rs[17] * S_TRI,
-            "k_bounce": rs[20] * (2 * 64.0 + 5.0) + rs[22] * S_NODE + rs[21] * S_TRI,
+            # (mirror rays walk the four-wide tree privately: a 128-byte node per lane and step)
+            "k_bounce": rs[20] * (2 * 64.0 + 5.0) + rs[22] * S_PKT_NODE + rs[21] * S_TRI,
         }
         dom = max(kt.items(), key=lambda kv: kv[1][0]) if kt else ("none", (float("nan"), 0))
         dom_name, dom_ms = dom[0], dom[1][0]
@@ -556,6 +557,8 @@ def main():
         traffic = (prof["traffic"].get(tkey) or {}).get(dom_name)
         prof_kernels = (prof["issue"] or {}).get("kernels") or {}
         prof_name = {"k_shaft": "k_shaft_pkt", "k_shadow": "k_shadow_cls", "k_shadow_fallback": "k_shadow_rays", "k_shaft_round2": "k_shaft"}.get(dom_name, dom_name)
+        if dom_name == "k_bounce" and "k_bounce_walk" in prof_kernels:
+            prof_name = "k_bounce_walk"                                  # the level's walk kernel (prepare / finish run at full lanes)
         issue_achieved = prof_kernels.get(prof_name, {}).get("useful_lane_ops_per_s")
         # ---- measured copy bandwidth of THIS device ("use the measured number as the denominator and state both"): a 1 GiB
         #      device-to-device copy of float4 elements, best of 5 ----

@@ -14,8 +14,12 @@ shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(d
 shutil.copy(os.path.join(src, "bench_trace.json"), os.path.join(dst, "bench_under_rocprof.json"))
 
 FAMILIES = ("k_primary", "k_cam_cones", "k_order_nodes", "k_ray_keys", "k_shaft_pkt", "k_shaft", "k_shadow_cls", "k_shadow_test", "k_shadow_wave", "k_shadow_rays",
-            "k_fb_expand", "k_fb_resolve", "k_bounce", "k_fold", "k_resolve", "k_post_process", "k_anti_alias")
-STATS_ARG = {"k_primary": 2, "k_shaft_pkt": 0, "k_shaft": 0, "k_shadow_cls": 1, "k_shadow_test": 1, "k_shadow_rays": 1, "k_shadow_wave": 1, "k_bounce": 1}
+            "k_fb_expand", "k_fb_resolve", "k_bounce_prep", "k_bounce_walk", "k_bounce_finish", "k_bounce", "k_fold", "k_resolve", "k_post_process", "k_anti_alias")
+STATS_ARG = {"k_primary": 2, "k_shaft_pkt": 0, "k_shaft": 0, "k_shadow_cls": 1, "k_shadow_test": 1, "k_shadow_rays": 1, "k_shadow_wave": 1, "k_bounce": 1,
+             "k_bounce_walk": 0, "k_bounce_finish": 1}
+
+
+BOUNCE = ("k_bounce_prep", "k_bounce_walk", "k_bounce_finish", "k_bounce")     # a level: prepare / walk / finish (or the one-kernel form)
 
 
 def family(name):
@@ -62,7 +66,8 @@ per_launch = {k: traffic[k] / max(1, len(launches[k])) for k in traffic}
 table = {"k_primary": per_launch.get("k_primary"), "k_shaft": per_launch.get("k_shaft_pkt"), "k_shaft_round2": per_launch.get("k_shaft"),
          "k_shadow": (2.0 * per_launch["k_shadow_cls"]) if "k_shadow_cls" in per_launch else None,
          "k_shadow_fallback": sum(per_launch.get(k, 0.0) for k in ("k_fb_expand", "k_shadow_rays", "k_fb_resolve", "k_shadow_wave")),
-         "k_bounce_per_level": per_launch.get("k_bounce"), "k_bounce": (traffic.get("k_bounce", 0.0) + traffic.get("k_fold", 0.0)) / max(1, len(launches.get("k_fold", ()))) if "k_bounce" in traffic else None,
+         "k_bounce_per_level": (sum(per_launch.get(k, 0.0) for k in BOUNCE) or None),
+         "k_bounce": (sum(traffic.get(k, 0.0) for k in BOUNCE + ("k_ray_keys", "k_fold")) / max(1, len(launches.get("k_fold", ())))) if any(k in traffic for k in BOUNCE) else None,
          "_launches_counted": {k: len(v) for k, v in launches.items()}}
 hb = {}
 if os.path.exists("profiles/hbm_traffic.json"):
@@ -74,7 +79,7 @@ hb[workload] = table
 hb["_how"] = ("HBM bytes per LAUNCH of each kernel = sum over its timed launches of (2*FETCH_SIZE + WRITE_SIZE)*1024 / number of launches, rocprofv3 --pmc "
               "FETCH_SIZE / --pmc WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B-per-lane loads on gfx950; "
               "bench.py --no-split: one launch per frame of k_primary / k_shaft (packet walk, round 1) / k_shaft_round2; `k_shadow` = the two launches of "
-              "k_shadow_cls of a frame (rounds 1 and 2) together; `k_bounce` = all levels' k_bounce launches + k_fold of one frame (what the K_BOUNCE event pair brackets)")
+              "k_shadow_cls of a frame (rounds 1 and 2) together; `k_bounce` = all levels' k_ray_keys / k_bounce_prep / k_bounce_walk / k_bounce_finish launches + k_fold of one frame (what the K_BOUNCE event pair brackets, less the device sort's own kernels)")
 hb.setdefault("_sources", {})[workload] = {"dir": dst, "command": "bash scripts/gpu_profile.sh %s ...   (bench.py --steps 2 --warmup 1 --no-split)" % tag}
 json.dump(hb, open("profiles/hbm_traffic.json", "w"), indent=1)
 
