@@ -44,12 +44,15 @@ for i in range(16):
     g.Add(Sphere(Vector(*c), 0.05 + 0.1 * rng.rand(), Color=pal[i % len(pal)]))
 r.ExtraGeometryToRaytrace = g
 dt = timed(r, 20)
-out.append({"config": "C1: 16 spheres + obj.3DS, 256x256, shading, reference tree (API round trip incl. D2H)", "ms": dt * 1e3, "Mrays_s": 256 * 256 / dt / 1e6})
+out.append({"config": "C1: 16 spheres + obj.3DS, 256x256, shading, default mode of the mirror (API round trip incl. D2H)", "ms": dt * 1e3, "Mrays_s": 256 * 256 / dt / 1e6})
 # C2: obj.3DS 1024^2 primary + shading, reference tree via the Renderer API
-for mode, name, literal in ((None, "default mode of the mirror (reference tree, shadow rays on the BVH, no counters)", False),
-                            (None, "reference tree, literal (gpuLiteralTraversalCounters)", True), (sa.MODE_BVH, "own BVH", False)):
+for mode, name, literal, thr in ((None, "default mode of the mirror (own BVH, no traversal counters)", False, None),
+                                 (None, "reference tree for the primary rays, shadow rays on the BVH, no counters (gpuOwnBvhThreshold = 5000)", False, 5000),
+                                 (None, "reference tree, literal (gpuLiteralTraversalCounters)", True, None)):
     r, px = setup(1024, 1.0, model_path=obj, mode=mode)
     r.gpuLiteralTraversalCounters = literal
+    if thr is not None:
+        r.gpuOwnBvhThreshold = thr
     dt = timed(r, 20)
     out.append({"config": "C2: obj.3DS (152 tris), 1024x1024, shading, %s (API round trip incl. D2H)" % name, "ms": dt * 1e3, "Mrays_s": 1024 * 1024 / dt / 1e6,
                 "NumRaysFired": r.NumRaysFired})
@@ -59,7 +62,7 @@ for mode, name, literal in ((None, "default mode of the mirror (reference tree, 
 # C3: 1M random triangles + BVH, 2048^2, shading + shadows
 from softray_amd.renderer import Model
 v9, argb, bmin, bmax = sa.unit_cube_scene(1000000)
-r, px = setup(2048, 1.5, model=Model.FromTriangles(v9, argb, bmin, bmax), mode=None)       # default mode: >= gpuOwnBvhThreshold triangles -> own BVH
+r, px = setup(2048, 1.5, model=Model.FromTriangles(v9, argb, bmin, bmax), mode=None)       # default mode: own BVH
 r.rayTraceShadows = True
 dt = timed(r, 5)
 out.append({"config": "C3: 1M random triangles + BVH, 2048x2048, shading + 100-sample shadows (API round trip incl. D2H)", "ms": dt * 1e3, "Mrays_s": 2048 * 2048 / dt / 1e6})

@@ -172,11 +172,11 @@ public:
     int rayTraceStartRow = 0, rayTraceEndRow = 0;
     // MI355X additions: which structure the device walks (-1: chosen per model, see Mode())
     int gpuTraceMode = -1;
-    // The drop-in default is the fast path: subdivided models of >= gpuOwnBvhThreshold triangles are traced
-    // through the library's own BVH; smaller ones keep the literal reference tree for their primary rays and answer their
-    // shadow rays on the BVH.  NumGeometryTests / NumNodeVisits / NumLeafNodeVisits then read 0 (NumRaysFired is exact).
+    // The drop-in default is the fast path: subdivided models of >= gpuOwnBvhThreshold triangles -- every model, by
+    // default -- are traced through the library's own BVH (same pixels); smaller ones keep the literal reference tree for their
+    // primary rays and answer their shadow rays on the BVH.  NumGeometryTests / NumNodeVisits / NumLeafNodeVisits then read 0 (NumRaysFired is exact).
     // gpuLiteralTraversalCounters = true: the literal tree traversal for every ray, with the reference's counters.
-    int gpuOwnBvhThreshold = 5000;
+    int gpuOwnBvhThreshold = 0;
     bool gpuLiteralTraversalCounters = false;
     int gpuMaxBounces = 0;          // config-5 extension: mirror bounces (0 = the reference's behaviour)
     double gpuReflectivity = 0.0;

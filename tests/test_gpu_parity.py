@@ -270,6 +270,33 @@ def test_random_scene_all_modes_vs_oracle_tree():
     assert len(np.unique(want)) > 1000
 
 
+def test_tiny_models_on_the_own_bvh():
+    """The host mirrors trace every subdivided model through the library's BVH by default: models of 1 ... 10 triangles (a single
+    leaf, a root with one or two children, device- and host-built) give the oracle's frames, with and without the 100-sample shadows."""
+    for n, both_sides in ((1, False), (1, True), (2, True), (3, True), (5, True)):
+        v9, argb, bmin, bmax = unit_cube_scene(n, seed=77 + n)
+        v9 = v9.copy()
+        v9[:, 1:, :] = v9[:, :1, :] + (v9[:, 1:, :] - v9[:, :1, :]) * 8.0      # big enough to be seen (and to shadow each other)
+        v9 = np.clip(v9, -0.5, 0.5)
+        if both_sides:                                                          # triangles are one-sided: one of each pair faces the camera
+            v9 = np.concatenate([v9, v9[:, [0, 2, 1], :]]); argb = np.concatenate([argb, argb])
+        v9 = np.ascontiguousarray(v9); argb = np.ascontiguousarray(argb)
+        o = orc.Scene(); o.set_triangles(v9, argb, bmin, bmax); assert o.build_tree() == 0
+        for on_device in (True, False):
+            g = sa.GpuScene(0)
+            g.set_triangles(v9, argb, bmin, bmax)
+            g.build((sa.MODE_BVH,), on_device=on_device)
+            for kw in (dict(), dict(shadows=True), dict(shadows=True, sub_pixel_res=2)):
+                f = make_frame(96, depth=1.5, **kw)
+                want, _ = o.render(f, threads=NCPU)
+                got, _ = g.render(as_sr(f, sa.MODE_BVH))
+                assert np.array_equal(got, want), (n, on_device, kw)
+                got2, _ = g.render(as_sr(f, sa.MODE_BVH), stats=False)
+                assert np.array_equal(got2, want), (n, on_device, kw, "no stats")
+        if both_sides:
+            assert len(np.unique(want)) > 2, n
+
+
 def test_rows_and_strips_on_gpu(obj_pair):
     g, o = obj_pair
     full, _ = g.render(as_sr(make_frame(80, 64, shadows=True)))
