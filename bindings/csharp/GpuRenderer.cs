@@ -174,7 +174,7 @@ namespace Engine3D.Hip
             }
         }
 
-        bool UsesOwnBvh(Model model) { return !LiteralTraversalCounters && model.Triangles.Count >= OwnBvhThreshold; }
+        bool UsesOwnBvh(Model model) { return !LiteralTraversalCounters && model.Triangles.Count >= System.Math.Max(1, OwnBvhThreshold); }
 
         /// The trace mode Render() should be given for `rayTraceSubdivision`: the reference tree (literal) or, for large models,
         /// the library's own BVH.

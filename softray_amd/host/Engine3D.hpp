@@ -324,7 +324,7 @@ private:
     int Mode() const {
         if (gpuTraceMode >= 0) return gpuTraceMode;
         if (!rayTraceSubdivision) return SR_MODE_BRUTE;
-        if (!gpuLiteralTraversalCounters && model_ && (int64_t)model_->argb.size() >= gpuOwnBvhThreshold) return SR_MODE_BVH;
+        if (!gpuLiteralTraversalCounters && model_ && (int64_t)model_->argb.size() >= std::max<int64_t>(1, gpuOwnBvhThreshold)) return SR_MODE_BVH;
         return SR_MODE_REF_TREE;
     }
     bool PinModel() {                                      // Renderer.cs:791-810

@@ -348,7 +348,7 @@ class Renderer:
             return self.gpuTraceMode
         if not self.rayTraceSubdivision:
             return MODE_BRUTE
-        if not self.gpuLiteralTraversalCounters and self._model is not None and len(self._model._argb) >= self.gpuOwnBvhThreshold:
+        if not self.gpuLiteralTraversalCounters and self._model is not None and len(self._model._argb) >= max(1, self.gpuOwnBvhThreshold):
             return MODE_BVH
         return MODE_REF_TREE
 
