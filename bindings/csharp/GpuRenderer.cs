@@ -107,15 +107,20 @@ namespace Engine3D.Hip
     {
         public const uint F_SHADING = 1, F_SHADOWS = 2, F_FOCAL_BLUR = 4, F_POINT_LIGHT = 8, F_SPECULAR = 16, F_STATIC_SHADOWS = 32;
         public const int MODE_REF_TREE = 0, MODE_BRUTE = 1, MODE_BVH = 2;
-        /// Models with at least this many triangles -- every model, by default -- are traced through the library's own BVH when the
-        /// caller asked for the subdivided path (rayTraceSubdivision): same pixels (include/softray.h SR_MODE_BVH), obj.3DS at 1024^2
-        /// in 0.17 instead of 0.37 ms, 10x faster soft shadows at 1 M triangles (the reference's 15-level tree holds >= 60 triangles
-        /// per leaf there).  int.MaxValue keeps every model on the literal reference tree.
-        public int OwnBvhThreshold = 0;
-        /// false (default): Render() does not ask for the three traversal counters (NumGeometryTests / NumNodeVisits /
-        /// NumLeafNodeVisits read 0, NumRaysFired is computed on the host), which lets the library use the own BVH and answer a
-        /// reference-tree frame's shadow rays on it.  true: the literal reference-tree traversal with the reference's counters.
-        public bool LiteralTraversalCounters = false;
+        /// How NumGeometryTests / NumNodeVisits / NumLeafNodeVisits (Renderer.cs:476-504) are answered -- an explicit choice of the
+        /// constructor, because they are the literal reference-tree traversal's counters and the fast path does not walk that tree.
+        ///   Literal  every model's primary rays walk the reference tree (SR_MODE_REF_TREE): the reference's counters, any model size;
+        ///   Auto     (default) models of fewer than OwnBvhThreshold triangles -- the sizes the reference itself handles -- as Literal,
+        ///            larger ones as Off;
+        ///   Off      every subdivided model on the library's own BVH; Render() then leaves CountersAvailable false and the patched
+        ///            Renderer getters throw InvalidOperationException (never a silent zero).
+        /// NumRaysFired is exact in every mode; shadow rays take the shaft path on the own BVH in all three (same pixels:
+        /// include/softray.h SR_MODE_BVH; obj.3DS at 1024^2: 0.36 ms literal, 0.17 ms on the own BVH).
+        public enum TraversalCounters { Auto, Literal, Off }
+        public readonly TraversalCounters Counters;
+        public int OwnBvhThreshold = 20000;
+        /// Did the last Render() produce the three traversal counters?  (false: it ran on the own BVH)
+        public bool CountersAvailable { get; private set; } = true;
         IntPtr scene;
         Model uploaded;                  // the model whose triangles the scene holds
         uint builtModes;                 // structures built for `uploaded` (bit 1 << mode)
@@ -126,16 +131,18 @@ namespace Engine3D.Hip
         GCHandle offsetsPin;
 
         /// <summary>One MI355X.</summary>
-        public SoftrayHip(int device = 0)
+        public SoftrayHip(int device = 0, TraversalCounters counters = TraversalCounters.Auto)
         {
+            Counters = counters;
             if (Native.sr_abi_version() != Native.AbiVersion) throw new InvalidOperationException("libsoftray_hip: ABI version mismatch");
             Native.Check(Native.sr_create(device, out scene));
         }
 
         /// <summary>A whole node from this one process: the frame's rows are split into interleaved 16-row strips over
         /// `devices` inside the library and copied straight into the caller's pixels (sr_create_multi).</summary>
-        public SoftrayHip(int[] devices)
+        public SoftrayHip(int[] devices, TraversalCounters counters = TraversalCounters.Auto)
         {
+            Counters = counters;
             if (Native.sr_abi_version() != Native.AbiVersion) throw new InvalidOperationException("libsoftray_hip: ABI version mismatch");
             Native.Check(Native.sr_create_multi(devices, devices.Length, out scene));
         }
@@ -165,8 +172,8 @@ namespace Engine3D.Hip
                 builtModes = 0;
             }
             uint bit = 1u << mode;
-            if (mode == MODE_REF_TREE && UsesOwnBvh(model)) bit = 1u << MODE_BVH;                    // large model: only the own BVH is needed
-            else if (mode == MODE_REF_TREE && !LiteralTraversalCounters) bit |= 1u << MODE_BVH;      // shadow rays of a tree frame take the shaft path
+            if (mode == MODE_REF_TREE && UsesOwnBvh(model)) bit = 1u << MODE_BVH;                    // large model (or Off): only the own BVH is needed
+            else if (mode == MODE_REF_TREE && model.Triangles.Count > 0) bit |= 1u << MODE_BVH;      // shadow rays of a tree frame take the shaft path
             if (mode != MODE_BRUTE && (builtModes & bit) != bit)
             {
                 Native.Check(Native.sr_build(scene, bit & ~builtModes, 0, 0));                       // SpatialSubdivision defaults 15 / 25
@@ -174,7 +181,11 @@ namespace Engine3D.Hip
             }
         }
 
-        bool UsesOwnBvh(Model model) { return !LiteralTraversalCounters && model.Triangles.Count >= System.Math.Max(1, OwnBvhThreshold); }
+        bool UsesOwnBvh(Model model)
+        {
+            if (model.Triangles.Count == 0 || Counters == TraversalCounters.Literal) return false;   // (an empty model: nothing to build a BVH from)
+            return Counters == TraversalCounters.Off || model.Triangles.Count >= OwnBvhThreshold;
+        }
 
         /// The trace mode Render() should be given for `rayTraceSubdivision`: the reference tree (literal) or, for large models,
         /// the library's own BVH.
@@ -256,10 +267,12 @@ namespace Engine3D.Hip
             frame.area_light_offsets = offsetsPin.AddrOfPinnedObject();
             for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) { frame.transform[4 * r + c] = transform[r, c]; frame.inv_transform[4 * r + c] = inverseTransform[r, c]; }
             // blocking; `pixels` is only touched during the call (the library pins it for the call and copies row bands into it while
-            // later bands still render).  Without LiteralTraversalCounters no counters are asked for: stats4 gets the rays fired only
-            ulong[] counters = LiteralTraversalCounters ? stats4 : null;
+            // later bands still render).  The literal tree (and brute force) produce the reference's counters; the own BVH does not:
+            // stats4 then gets the rays fired only and CountersAvailable turns false
+            CountersAvailable = mode != MODE_BVH;
+            ulong[] counters = CountersAvailable ? stats4 : null;
             Native.Check(Native.sr_render(scene, ref frame, pixels, counters), renderCall: true);
-            if (!LiteralTraversalCounters && stats4 != null)
+            if (!CountersAvailable && stats4 != null)
             {
                 int a = Math.Min(Math.Max(0, startRow), height - 1), b = Math.Min(Math.Max(0, endRow), height - 1);   // Renderer.cs:1652-1653
                 stats4[0] = b < a ? 0UL : (ulong)(b - a + 1) * (ulong)width * (ulong)(subPixelRes * subPixelRes);       // NumRaysFired (:1916)

@@ -72,9 +72,14 @@ enum {
                                      halves on two internal streams (the default: the latency-bound tail kernels of one
                                      half overlap the other half's work, -5 % frame time).  Same pixels; used to time
                                      kernels that do not share the GPU with another kernel                       */
-    SR_F_PER_LANE_SHADOWS = 1u << 9 /* library option: trace shadow samples one lane per hit point (k_shadow)
+    SR_F_PER_LANE_SHADOWS = 1u << 9, /* library option: trace shadow samples one lane per hit point (k_shadow)
                                      instead of one wavefront per hit point with a shared shaft walk
                                      (k_shadow_packet).  Pixels are identical; cross-check                  */
+    SR_F_LITERAL_SECONDARY = 1u << 11 /* library option: a SR_MODE_REF_TREE frame traces its SHADOW rays through the reference tree
+                                     too.  By default (own BVH built, point light, <= 1024 samples) they are answered on the
+                                     library's BVH (shaft path): "is there a hit with rayFrac <= 1.0" has the same answer, and the
+                                     four statistics of sr_render count the primary rays, which keep the literal traversal either
+                                     way.  With the flag the secondary counters of sr_last_ray_stats are the reference tree's  */
 };
 
 /* how the model's triangles are intersected */
@@ -339,7 +344,7 @@ enum {
                                     does for a part whose memory the first device cannot read; test hook for that path                 */
     SR_DBG_LITERAL_SHADOWS = 15, /* > 0: no shortcut for ShadowMethod -- a directional light's samples are traced one by one although all of
                                     them provably escape, and a SR_MODE_REF_TREE frame traces its shadow rays through the reference tree
-                                    even when the caller does not ask for the traversal counters; cross-checks of both shortcuts      */
+                                    (as with SR_F_LITERAL_SECONDARY); cross-checks of both shortcuts                                  */
     SR_DBG_COUNT          = 16
 };
 int  sr_debug_set(sr_scene*, int32_t key, int64_t value);

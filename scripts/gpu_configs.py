@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import softray_amd as sa
-from softray_amd.renderer import Renderer, Instance, Vector, Sphere, Color, GeometryCollection
+from softray_amd.renderer import Renderer, Instance, Vector, Sphere, Color, GeometryCollection, TraversalCounters
 
 def timed(r, n=5):
     r.Render()                                  # warm-up (uploads, builds)
@@ -13,8 +13,8 @@ def timed(r, n=5):
         r.Render()
     return (time.perf_counter() - t) / n
 
-def setup(res, depth, model_path=None, model=None, mode=None):
-    r = Renderer()
+def setup(res, depth, model_path=None, model=None, mode=None, counters=TraversalCounters.Auto):
+    r = Renderer(0, traversalCounters=counters)
     r.BackgroundColor = 0xff00ff
     px = np.zeros(res * res, dtype=np.int32)
     r.SetRenderingSurface(res, res, px)
@@ -46,23 +46,29 @@ r.ExtraGeometryToRaytrace = g
 dt = timed(r, 20)
 out.append({"config": "C1: 16 spheres + obj.3DS, 256x256, shading, default mode of the mirror (API round trip incl. D2H)", "ms": dt * 1e3, "Mrays_s": 256 * 256 / dt / 1e6})
 # C2: obj.3DS 1024^2 primary + shading, reference tree via the Renderer API
-for mode, name, literal, thr in ((None, "default mode of the mirror (own BVH, no traversal counters)", False, None),
-                                 (None, "reference tree for the primary rays, shadow rays on the BVH, no counters (gpuOwnBvhThreshold = 5000)", False, 5000),
-                                 (None, "reference tree, literal (gpuLiteralTraversalCounters)", True, None)):
-    r, px = setup(1024, 1.0, model_path=obj, mode=mode)
-    r.gpuLiteralTraversalCounters = literal
-    if thr is not None:
-        r.gpuOwnBvhThreshold = thr
+for name, counters in (("TraversalCounters.Auto = the default: literal reference tree + counters for this model size, shadow rays on the BVH", TraversalCounters.Auto),
+                       ("TraversalCounters.Off: own BVH, no traversal counters", TraversalCounters.Off)):
+    r, px = setup(1024, 1.0, model_path=obj, counters=counters)
     dt = timed(r, 20)
     out.append({"config": "C2: obj.3DS (152 tris), 1024x1024, shading, %s (API round trip incl. D2H)" % name, "ms": dt * 1e3, "Mrays_s": 1024 * 1024 / dt / 1e6,
                 "NumRaysFired": r.NumRaysFired})
     r.rayTraceShadows = True
     dt = timed(r, 5)
     out.append({"config": "C2 + 100-sample soft shadows, %s" % name, "ms": dt * 1e3, "Mrays_s": 1024 * 1024 / dt / 1e6})
+# the Auto threshold: a 19 999-triangle soup on the literal tree (Auto) against the own BVH (Off), 1024^2
+from softray_amd.renderer import Model
+v9s, argbs, bmins, bmaxs = sa.unit_cube_scene(19999)
+for name, counters in (("Auto (literal tree + counters)", TraversalCounters.Auto), ("Off (own BVH)", TraversalCounters.Off)):
+    r, px = setup(1024, 1.5, model=Model.FromTriangles(v9s, argbs, bmins, bmaxs), counters=counters)
+    dt = timed(r, 10)
+    out.append({"config": "19 999 random triangles, 1024x1024, shading, %s" % name, "ms": dt * 1e3, "Mrays_s": 1024 * 1024 / dt / 1e6})
+    r.rayTraceShadows = True
+    dt = timed(r, 5)
+    out.append({"config": "19 999 random triangles + 100-sample soft shadows, %s" % name, "ms": dt * 1e3, "Mrays_s": 1024 * 1024 / dt / 1e6})
 # C3: 1M random triangles + BVH, 2048^2, shading + shadows
 from softray_amd.renderer import Model
 v9, argb, bmin, bmax = sa.unit_cube_scene(1000000)
-r, px = setup(2048, 1.5, model=Model.FromTriangles(v9, argb, bmin, bmax), mode=None)       # default mode: own BVH
+r, px = setup(2048, 1.5, model=Model.FromTriangles(v9, argb, bmin, bmax))       # default mode: own BVH at this size
 r.rayTraceShadows = True
 dt = timed(r, 5)
 out.append({"config": "C3: 1M random triangles + BVH, 2048x2048, shading + 100-sample shadows (API round trip incl. D2H)", "ms": dt * 1e3, "Mrays_s": 2048 * 2048 / dt / 1e6})

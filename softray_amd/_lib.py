@@ -18,6 +18,7 @@ F_SHADING, F_SHADOWS, F_FOCAL_BLUR, F_POINT_LIGHT, F_SPECULAR, F_STATIC_SHADOWS 
 F_SINGLE_KERNEL = 1 << 8
 F_PER_LANE_SHADOWS = 1 << 9
 F_NO_SPLIT = 1 << 10
+F_LITERAL_SECONDARY = 1 << 11
 MODE_REF_TREE, MODE_BRUTE, MODE_BVH = 0, 1, 2
 TARGET_ROOT = 0x100
 BUILD_ON_DEVICE = 0x100

@@ -487,9 +487,11 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             fc.flags = (fc.flags & ~(uint32_t)SR_F_SHADOWS) | sr::kFlagAllSamplesEscape;
         }
     }
-    // (2) a REF_TREE frame whose caller does not read the traversal counters: the shadow rays only answer "is there a hit with
-    //     rayFrac <= 1.0", which the own BVH answers identically (include/softray.h SR_MODE_BVH) -- they take the shaft path
-    const bool shadows_on_bvh = (fc.flags & SR_F_SHADOWS) && f->trace_mode == SR_MODE_REF_TREE && !d_stats && s->bvh.built && !static_shadows &&
+    // (2) a REF_TREE frame: the shadow rays only answer "is there a hit with rayFrac <= 1.0", which the own BVH answers identically
+    //     (include/softray.h SR_MODE_BVH) -- they take the shaft path.  The four statistics of sr_render count the PRIMARY rays, which
+    //     keep the literal traversal, so a caller that reads them loses nothing; SR_F_LITERAL_SECONDARY asks for the literal traversal
+    //     of the shadow rays too (their counters in sr_last_ray_stats are then the reference tree's)
+    const bool shadows_on_bvh = (fc.flags & SR_F_SHADOWS) && f->trace_mode == SR_MODE_REF_TREE && !(f->flags & SR_F_LITERAL_SECONDARY) && s->bvh.built && !static_shadows &&
                                 (fc.flags & SR_F_POINT_LIGHT) && fc.shadow_samples <= kMaxShaftSamples && f->max_bounces == 0 &&
                                 !(f->flags & (SR_F_SINGLE_KERNEL | SR_F_PER_LANE_SHADOWS)) && s->dbg[SR_DBG_LITERAL_SHADOWS] <= 0;
     if (shadows_on_bvh && (rc = sync_geometry(s, SR_MODE_BVH))) return rc;

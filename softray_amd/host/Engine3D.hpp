@@ -172,18 +172,24 @@ public:
     int rayTraceStartRow = 0, rayTraceEndRow = 0;
     // MI355X additions: which structure the device walks (-1: chosen per model, see Mode())
     int gpuTraceMode = -1;
-    // The drop-in default is the fast path: subdivided models of >= gpuOwnBvhThreshold triangles -- every model, by
-    // default -- are traced through the library's own BVH (same pixels); smaller ones keep the literal reference tree for their
-    // primary rays and answer their shadow rays on the BVH.  NumGeometryTests / NumNodeVisits / NumLeafNodeVisits then read 0 (NumRaysFired is exact).
-    // gpuLiteralTraversalCounters = true: the literal tree traversal for every ray, with the reference's counters.
-    int gpuOwnBvhThreshold = 0;
-    bool gpuLiteralTraversalCounters = false;
+    // How NumGeometryTests / NumNodeVisits / NumLeafNodeVisits (Renderer.cs:476-504) are answered is an explicit choice of the
+    // constructor: they are the literal reference-tree traversal's counters, and the fast path does not walk that tree.
+    //   Literal  every model's primary rays walk the reference tree (SR_MODE_REF_TREE): the reference's counters, any model size;
+    //   Auto     (default) models of fewer than gpuOwnBvhThreshold triangles -- the sizes the reference itself handles -- as Literal,
+    //            larger ones as Off;
+    //   Off      every subdivided model on the library's own BVH; reading one of the three counters throws InvalidOperationException
+    //            (never a silent zero).
+    // NumRaysFired is exact in every mode; shadow rays take the shaft path on the own BVH in all three (same pixels).
+    enum class TraversalCounters { Auto, Literal, Off };
+    const TraversalCounters gpuTraversalCounters;
+    int gpuOwnBvhThreshold = 20000;
     int gpuMaxBounces = 0;          // config-5 extension: mirror bounces (0 = the reference's behaviour)
     double gpuReflectivity = 0.0;
     std::vector<std::shared_ptr<Instance>> Instances;
     Raytrace::GeometryCollection ExtraGeometryToRaytrace;
 
-    explicit Renderer(int device = 0) {                    // Renderer.cs:207-230
+    explicit Renderer(int device = 0, TraversalCounters traversalCounters = TraversalCounters::Auto)   // Renderer.cs:207-230
+        : gpuTraversalCounters(traversalCounters) {
         directionalLight_dir = Vector(-1, -1, 1);
         directionalLight_dir.Normalise();
         positionalLight_pos = Vector(0.0, 0.0, 1.5) - directionalLight_dir * 2;
@@ -253,7 +259,8 @@ public:
         }
         int mode = Mode();
         uint32_t want = mode == SR_MODE_BRUTE ? 0u : (1u << mode);
-        if (mode == SR_MODE_REF_TREE && !gpuLiteralTraversalCounters) want |= 1u << SR_MODE_BVH;   // a tree frame's shadow rays take the BVH's shaft path
+        if (mode == SR_MODE_REF_TREE && rayTraceShadows && !rayTraceShadowsStatic && !model_->argb.empty())
+            want |= 1u << SR_MODE_BVH;                     // a tree frame's shadow rays take the BVH's shaft path
         if (want & ~built_) {
             sr_check(sr_build(scene_, want & ~built_, 0, 0));  // SpatialSubdivision defaults 15 / 25
             built_ |= want;
@@ -273,9 +280,10 @@ public:
     }
     // Renderer.cs:465-504
     int64_t NumRaysFired() const { return (int64_t)stats_[0]; }
-    int64_t NumGeometryTests() const { return (int64_t)stats_[1]; }
-    int64_t NumNodeVisits() const { return (int64_t)stats_[2]; }
-    int64_t NumLeafNodeVisits() const { return (int64_t)stats_[3]; }
+    int64_t NumGeometryTests() const { return Counter(1, "NumGeometryTests"); }
+    int64_t NumNodeVisits() const { return Counter(2, "NumNodeVisits"); }
+    int64_t NumLeafNodeVisits() const { return Counter(3, "NumLeafNodeVisits"); }
+    bool TraversalCountersAvailable() const { return haveCounters_; }
 
     sr_frame BuildFrame(const Instance& instance) const {  // the host half of RaytraceGeometry, :1510-1528,:1652
         sr_frame f{};
@@ -321,11 +329,22 @@ private:
         if (antiAliasResolution_ < 2) return;
         sr_check(sr_anti_alias(scene_, pixels_, aaWidth_, aaHeight_, antiAliasResolution_, aaPixels_));
     }
+    int64_t Counter(int i, const char* name) const {
+        if (!haveCounters_)
+            throw InvalidOperationException(std::string(name) + ": the last frame ran on the library's own BVH, which does not produce the reference "
+                                            "tree's traversal counters; construct the Renderer with TraversalCounters::Literal (or raise gpuOwnBvhThreshold)");
+        return (int64_t)stats_[i];
+    }
+    bool Literal() const {                                 // do the model's primary rays walk the reference tree (and produce its counters)?
+        if (model_ && model_->argb.empty()) return true;   // an empty model: nothing to build a BVH from
+        if (gpuTraversalCounters == TraversalCounters::Literal) return true;
+        if (gpuTraversalCounters == TraversalCounters::Off) return false;
+        return !model_ || (int64_t)model_->argb.size() < (int64_t)gpuOwnBvhThreshold;
+    }
     int Mode() const {
         if (gpuTraceMode >= 0) return gpuTraceMode;
         if (!rayTraceSubdivision) return SR_MODE_BRUTE;
-        if (!gpuLiteralTraversalCounters && model_ && (int64_t)model_->argb.size() >= std::max<int64_t>(1, gpuOwnBvhThreshold)) return SR_MODE_BVH;
-        return SR_MODE_REF_TREE;
+        return Literal() ? SR_MODE_REF_TREE : SR_MODE_BVH;
     }
     bool PinModel() {                                      // Renderer.cs:791-810
         if (!modelVolatile_) return false;
@@ -340,13 +359,15 @@ private:
         rayTraceEndRow = std::min(std::max(0, rayTraceEndRow), height_ - 1);
         sr_frame f = BuildFrame(instance);
         if (!pixels_) throw InvalidOperationException("SetRenderingSurface must be called before Render");
-        if (gpuLiteralTraversalCounters) {
+        if (f.trace_mode != SR_MODE_BVH) {                 // the literal tree (or brute force): the reference's counters
             sr_check(sr_render(scene_, &f, pixels_, stats_));
-        } else {                                           // no counters asked for: the library may take its shortcuts
+            haveCounters_ = true;
+        } else {                                           // the own BVH does not produce them: reading one throws
             sr_check(sr_render(scene_, &f, pixels_, nullptr));
             const int rows = std::max(0, rayTraceEndRow - rayTraceStartRow + 1);
             stats_[0] = (uint64_t)rows * (uint64_t)width_ * (uint64_t)(rayTraceSubPixelRes * rayTraceSubPixelRes);   // NumRaysFired, :1916
             stats_[1] = stats_[2] = stats_[3] = 0;
+            haveCounters_ = false;
         }
     }
 
@@ -363,6 +384,7 @@ private:
     const Engine3D::Model* sceneModel_ = nullptr;
     uint32_t built_ = 0;
     uint64_t stats_[4] = {0, 0, 0, 0};
+    bool haveCounters_ = true;                             // before the first frame the reference reads zeros
 };
 
 }  // namespace Engine3D

@@ -173,6 +173,25 @@ class Instance:
         self.Yaw, self.Pitch, self.Roll = Yaw, Pitch, Roll
 
 
+class TraversalCounters:
+    """How a Renderer of this library answers NumGeometryTests / NumNodeVisits / NumLeafNodeVisits (Renderer.cs:476-504) -- an
+    explicit choice of the constructor, because the counters are the literal reference-tree traversal's and the fast path does
+    not walk that tree:
+
+    Literal  every model's primary rays walk the reference tree literally (SR_MODE_REF_TREE); the three counters are the
+             reference's, for any model size (slow for large models);
+    Auto     (default) models of fewer than gpuOwnBvhThreshold triangles -- the sizes the reference itself handles -- as Literal;
+             larger ones as Off;
+    Off      every subdivided model on the library's own BVH; reading one of the three counters raises InvalidOperationException
+             (they are never silently zero).
+    NumRaysFired is exact in every mode.  Shadow rays take the shaft path on the own BVH in all three (same pixels)."""
+    Auto, Literal, Off = range(3)
+
+
+class InvalidOperationException(RuntimeError):
+    """System.InvalidOperationException: a traversal counter was read although the frame did not produce it."""
+
+
 class Style:
     """Renderer.Style (Renderer.cs:23-33): "style of rendering (actually post-processing)"."""
     Standard, ColorShuffle, Negative, DepthSmooth, DepthBanded, Normals, Count = range(7)
@@ -183,7 +202,12 @@ class Renderer:
 
     Style = Style
 
-    def __init__(self, device=0):
+    TraversalCounters = TraversalCounters
+
+    def __init__(self, device=0, traversalCounters=TraversalCounters.Auto):
+        if traversalCounters not in (TraversalCounters.Auto, TraversalCounters.Literal, TraversalCounters.Off):
+            raise ValueError("traversalCounters must be TraversalCounters.Auto, .Literal or .Off")
+        self.gpuTraversalCounters = traversalCounters
         self.RenderStyle = Style.Standard                          # Renderer.cs:35
         self.depthBuffer = False                                   # Renderer.cs:56-57 (only steer the two depth styles here)
         self.depthBufferHires = False
@@ -216,13 +240,13 @@ class Renderer:
         self.rayTraceEndRow = 0
         # MI355X additions (not in the reference): which acceleration structure the device walks
         self.gpuTraceMode = None              # None: chosen per model (see _mode); or MODE_REF_TREE / MODE_BRUTE / MODE_BVH
-        # the drop-in default is the fast path: subdivided models of >= gpuOwnBvhThreshold triangles -- every model, by
-        # default -- are traced through the library's own BVH (same pixels; obj.3DS at 1024^2: 0.17 instead of 0.37 ms); smaller ones
-        # keep the literal reference tree for their primary rays and answer their shadow rays on the BVH.  NumGeometryTests /
-        # NumNodeVisits / NumLeafNodeVisits then read 0.  gpuLiteralTraversalCounters = True: the literal tree traversal for every
-        # ray, with the reference's counters
-        self.gpuOwnBvhThreshold = 0
-        self.gpuLiteralTraversalCounters = False
+        # Which structure a subdivided model's primary rays walk follows from the constructor's TraversalCounters choice: the literal
+        # reference tree (with the reference's three counters) for every model (Literal), for models below gpuOwnBvhThreshold
+        # triangles (Auto, the default), or for none (Off: the own BVH; the counters then raise instead of reading zero).  Same
+        # pixels either way except for the documented 1e-10 leaf-face case (include/softray.h SR_MODE_BVH), which is one more
+        # reason why models of the reference's own sizes keep the literal tree by default.  obj.3DS at 1024^2: 0.36 ms literal,
+        # 0.17 ms on the own BVH
+        self.gpuOwnBvhThreshold = 20000
         self.gpuTreeMaxDepth = 0              # 0 => SpatialSubdivision defaults 15 / 25
         self.gpuTreeMaxGeometryPerNode = 0
         self.gpuMaxBounces = 0                # config-5 extension: mirror bounces (0 = reference behaviour)
@@ -243,6 +267,7 @@ class Renderer:
         self._sceneModel = None
         self._extraSig = None
         self._stats = np.zeros(4, dtype=np.uint64)
+        self._haveCounters = True                                  # before the first frame the reference reads zeros
 
     # ---- properties ----
     @property
@@ -293,9 +318,18 @@ class Renderer:
             value.LoadingError = False
 
     NumRaysFired = property(lambda self: int(self._stats[0]))     # Renderer.cs:465-504
-    NumGeometryTests = property(lambda self: int(self._stats[1]))
-    NumNodeVisits = property(lambda self: int(self._stats[2]))
-    NumLeafNodeVisits = property(lambda self: int(self._stats[3]))
+
+    def _counter(self, i, name):
+        if not self._haveCounters:
+            raise InvalidOperationException(
+                "%s: the last frame ran on the library's own BVH, which does not produce the reference tree's traversal counters; "
+                "construct the Renderer with traversalCounters=TraversalCounters.Literal (or raise gpuOwnBvhThreshold) to get them" % name)
+        return int(self._stats[i])
+
+    NumGeometryTests = property(lambda self: self._counter(1, "NumGeometryTests"))
+    NumNodeVisits = property(lambda self: self._counter(2, "NumNodeVisits"))
+    NumLeafNodeVisits = property(lambda self: self._counter(3, "NumLeafNodeVisits"))
+    TraversalCountersAvailable = property(lambda self: bool(self._haveCounters))
     RenderingSurfaceWidth = property(lambda self: self._width)
     RenderingSurfaceHeight = property(lambda self: self._height)
 
@@ -343,14 +377,22 @@ class Renderer:
             return True
         return self._model is not None
 
+    def _literal(self):
+        """Do the model's primary rays walk the reference tree (and produce its counters)?"""
+        if self._model is not None and len(self._model._argb) == 0:
+            return True                                            # an empty model: nothing to build a BVH from
+        if self.gpuTraversalCounters == TraversalCounters.Literal:
+            return True
+        if self.gpuTraversalCounters == TraversalCounters.Off:
+            return False
+        return self._model is None or len(self._model._argb) < self.gpuOwnBvhThreshold
+
     def _mode(self):
         if self.gpuTraceMode is not None:
             return self.gpuTraceMode
         if not self.rayTraceSubdivision:
             return MODE_BRUTE
-        if not self.gpuLiteralTraversalCounters and self._model is not None and len(self._model._argb) >= max(1, self.gpuOwnBvhThreshold):
-            return MODE_BVH
-        return MODE_REF_TREE
+        return MODE_REF_TREE if self._literal() else MODE_BVH
 
     def PreCalculate(self):
         """Renderer.cs:673-699: MakeRayTracableGeometry_simple / _subdivided, here = upload + build on demand."""
@@ -365,7 +407,7 @@ class Renderer:
             self._built = set()
         mode = self._mode()
         want = set() if mode == MODE_BRUTE else {mode}
-        if mode == MODE_REF_TREE and not self.gpuLiteralTraversalCounters:
+        if mode == MODE_REF_TREE and self.rayTraceShadows and not self.rayTraceShadowsStatic and len(self._model._argb) > 0:
             want.add(MODE_BVH)                                     # a tree frame's shadow rays take the BVH's shaft path
         need = tuple(sorted(want - self._built))
         if need:
@@ -471,13 +513,15 @@ class Renderer:
         self.rayTraceEndRow = min(max(0, self.rayTraceEndRow), self._height - 1)
         frame = self.BuildFrame(instance)
         view = self._pixels.reshape(-1)[: self._width * self._height]
-        if self.gpuLiteralTraversalCounters:
+        if frame.trace_mode != MODE_BVH:                           # the literal tree (or brute force): the reference's counters
             _, self._stats = self._scene.render(frame, out=view, stats=True)
-        else:                                                      # no counters asked for: the library may take its shortcuts
+            self._haveCounters = True
+        else:                                                      # the own BVH does not produce them: reading one raises
             self._scene.render(frame, out=view, stats=False)
             rows = max(0, self.rayTraceEndRow - self.rayTraceStartRow + 1)
             self._stats = np.array([rows * self._width * self.rayTraceSubPixelRes ** 2, 0, 0, 0], dtype=np.uint64)   # NumRaysFired, Renderer.cs:1916
+            self._haveCounters = False
 
 
-__all__ = ["Renderer", "Style", "Instance", "Model", "GeometryCollection", "Sphere", "Plane", "Triangle", "Vector", "Color",
+__all__ = ["Renderer", "Style", "TraversalCounters", "InvalidOperationException", "Instance", "Model", "GeometryCollection", "Sphere", "Plane", "Triangle", "Vector", "Color",
            "MODE_REF_TREE", "MODE_BRUTE", "MODE_BVH"]

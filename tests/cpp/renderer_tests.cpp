@@ -1,6 +1,9 @@
 // renderer_tests.cpp -- the reference's golden-image tests (Engine3D-Tests/Raytrace/RendererTests.cs) driven through
 // the C++ host mirror softray_amd/host/Engine3D.hpp, i.e. through the same API a C# caller uses.
-// usage: renderer_tests <golden-dir>      exit 0 = every scenario has 0 differing RGB pixels
+// usage: renderer_tests <golden-dir>                      exit 0 = every scenario has 0 differing RGB pixels
+//        renderer_tests <golden-dir> --dump-c2 <prefix>   config C2 (obj.3DS, 1024^2; without and with shadows) in the default mode,
+//                                                         raw int32 pixels to <prefix>_c2.bin / <prefix>_c2_shadows.bin (the pytest
+//                                                         side compares every 16-row strip with the oracle's fixture)
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -48,11 +51,19 @@ static void RendererSetup(Renderer& renderer, const std::string& modelFileName, 
 }
 
 // RendererTests.RaytraceScenario (RendererTests.cs:381-459), in-scope flags only
+using TC = Renderer::TraversalCounters;
+static const char* TcName(TC tc) { return tc == TC::Auto ? "Auto" : tc == TC::Literal ? "Literal" : "Off"; }
+
 static int RaytraceScenario(const std::string& dir, bool shading, bool focalBlur, bool shadows, int subPixelRes, int resolution,
-                            bool staticShadows = false) {
+                            bool staticShadows = false, TC tc = TC::Auto, bool twoInstances = false) {
     const double objectDepth = 1.0;
-    Renderer renderer(0);
+    Renderer renderer(0, tc);
     RendererSetup(renderer, dir + "/obj.3ds", -22.0, 135.0, 0.0, objectDepth, resolution);
+    if (twoInstances) {                                     // Renderer.cs:746-760: every instance is raytraced over the whole surface; the last one stays
+        auto first = std::make_shared<Instance>(renderer.Model());
+        first->Position = Vector(0.0, 0.0, 2.0); first->Yaw = 10.0 / 180.0 * kPi; first->Pitch = 0.3; first->Roll = 0.1;
+        renderer.Instances.insert(renderer.Instances.begin(), first);
+    }
     renderer.rayTrace = true;
     renderer.rayTraceSubdivision = true;
     renderer.rayTraceShading = shading;
@@ -65,13 +76,40 @@ static int RaytraceScenario(const std::string& dir, bool shading, bool focalBlur
                        (focalBlur ? "x" + std::to_string(subPixelRes) : (subPixelRes > 1 ? "_" + std::to_string(subPixelRes) + "xAA" : ""));
     std::string path = dir + "/raytrace/" + std::to_string(resolution) + "x" + std::to_string(resolution) + "/" + name + ".bmp";
     renderer.Render();
-    int w, h; std::vector<uint32_t> base;
+    int w = 0, h = 0; std::vector<uint32_t> base;
     if (!ReadBmpRgb(path, w, h, base) || w != resolution || h != resolution) { std::printf("%-40s MISSING BASELINE\n", name.c_str()); return 1; }
     int diff = 0;
     for (int i = 0; i < w * h; ++i) if (((uint32_t)pixels[i] & 0x00FFFFFFu) != base[i]) ++diff;
-    std::printf("%-36s %3dx%-3d diff=%d rays=%lld nodeVisits=%lld\n", name.c_str(), w, h, diff, (long long)renderer.NumRaysFired(),
-                (long long)renderer.NumNodeVisits());
-    return diff == 0 ? 0 : 1;
+    int bad = diff == 0 ? 0 : 1;
+    long long nodeVisits = -1;
+    if (renderer.TraversalCountersAvailable()) {            // the literal tree: the reference's counters
+        nodeVisits = (long long)renderer.NumNodeVisits();
+        if (nodeVisits <= 0 || renderer.NumGeometryTests() <= 0 || tc == TC::Off) ++bad;
+    } else {                                                // the own BVH: the counters are not produced and say so loudly
+        if (tc != TC::Off) ++bad;
+        try { (void)renderer.NumNodeVisits(); ++bad; std::printf("expected InvalidOperationException from NumNodeVisits\n"); }
+        catch (const InvalidOperationException&) {}
+    }
+    if (renderer.NumRaysFired() != (int64_t)resolution * resolution * subPixelRes * subPixelRes) ++bad;
+    std::printf("%-36s %3dx%-3d %-7s%s diff=%d rays=%lld nodeVisits=%lld%s\n", name.c_str(), w, h, TcName(tc), twoInstances ? " 2 instances" : "", diff,
+                (long long)renderer.NumRaysFired(), nodeVisits, bad ? "  <-- FAILED" : "");
+    return bad;
+}
+
+// config C2 through the mirror's DEFAULT mode: raw pixels for the pytest side (tests/golden/frames/c2*.json)
+static int DumpC2(const std::string& dir, const std::string& prefix) {
+    std::vector<int32_t> big(1024 * 1024);
+    for (int shadows = 0; shadows < 2; ++shadows) {
+        Renderer renderer(0);
+        RendererSetup(renderer, dir + "/obj.3ds", -22.0, 135.0, 0.0, 1.0, 1024);
+        renderer.SetRenderingSurface(1024, 1024, big.data());
+        renderer.rayTrace = true; renderer.rayTraceFocalBlur = false; renderer.rayTraceShadows = shadows != 0;
+        renderer.Render();
+        std::ofstream out(prefix + (shadows ? "_c2_shadows.bin" : "_c2.bin"), std::ios::binary);
+        out.write((const char*)big.data(), (std::streamsize)(big.size() * sizeof(int32_t)));
+        if (!out) return 1;
+    }
+    return 0;
 }
 
 // Render() = raytrace + PostProcessImage + AntiAliasImage (Renderer.cs:746-767): the Negative style at AntiAliasResolution 2
@@ -113,18 +151,29 @@ int main(int argc, char** argv) {
     if (argc < 2) { std::fprintf(stderr, "usage: %s <golden-dir>\n", argv[0]); return 2; }
     std::string dir = argv[1];
     try {
+        if (argc >= 4 && std::string(argv[2]) == "--dump-c2") return DumpC2(dir, argv[3]);
         int bad = 0;
-        bad += RaytraceScenario(dir, true, false, false, 1, 100);       // shading
-        bad += RaytraceScenario(dir, false, false, false, 1, 100);      // noShading
-        bad += RaytraceScenario(dir, true, false, false, 2, 100);       // RaytraceAntialised (RendererTests.cs:140-149)
-        bad += RaytraceScenario(dir, true, false, false, 4, 100);
-        bad += RaytraceScenario(dir, true, false, false, 8, 100);
-        bad += RaytraceScenario(dir, true, false, true, 1, 100);        // RaytraceDynamicShadow (:154-160)
-        bad += RaytraceScenario(dir, true, true, true, 4, 50);          // RaytraceShadowAndFocalBlur (:179-188)
-        bad += RaytraceScenario(dir, true, false, true, 4, 50);         // RaytraceShadowAndAntiAlias (:207-213)
-        bad += RaytraceScenario(dir, true, true, false, 2, 100);
-        bad += RaytraceScenario(dir, true, false, true, 1, 100, true);  // RaytraceStaticShadow (:167-175)
-        bad += RaytraceScenario(dir, false, false, true, 1, 100, true);
+        // all 22 goldens of RendererTests (RendererTests.cs:140-213, 381-430) in every TraversalCounters mode
+        for (TC tc : {TC::Auto, TC::Literal, TC::Off}) {
+            for (int shading = 1; shading >= 0; --shading) {
+                bad += RaytraceScenario(dir, shading, false, false, 1, 100, false, tc);   // shading / noShading
+                bad += RaytraceScenario(dir, shading, false, false, 4, 100, false, tc);   // _4xAA
+                bad += RaytraceScenario(dir, shading, true, false, 2, 100, false, tc);    // _focalBlurx2
+                bad += RaytraceScenario(dir, shading, true, false, 4, 100, false, tc);    // _focalBlurx4
+                bad += RaytraceScenario(dir, shading, false, true, 1, 100, false, tc);    // RaytraceDynamicShadow (:154-160)
+                bad += RaytraceScenario(dir, shading, false, true, 4, 100, false, tc);    // _shadows_4xAA
+                bad += RaytraceScenario(dir, shading, true, true, 2, 100, false, tc);     // _shadows_focalBlurx2
+                bad += RaytraceScenario(dir, shading, true, true, 4, 100, false, tc);     // _shadows_focalBlurx4
+                bad += RaytraceScenario(dir, shading, false, true, 1, 100, true, tc);     // RaytraceStaticShadow (:167-175)
+            }
+            bad += RaytraceScenario(dir, true, false, false, 2, 100, false, tc);          // RaytraceAntialised (:140-149)
+            bad += RaytraceScenario(dir, true, false, false, 8, 100, false, tc);
+            bad += RaytraceScenario(dir, true, true, true, 4, 50, false, tc);             // RaytraceShadowAndFocalBlur (:179-188)
+            bad += RaytraceScenario(dir, true, false, true, 4, 50, false, tc);            // RaytraceShadowAndAntiAlias (:207-213)
+            // two instances: the last one (the goldens' pose) owns every pixel (Renderer.cs:746-760)
+            bad += RaytraceScenario(dir, true, false, false, 1, 100, false, tc, true);
+            bad += RaytraceScenario(dir, true, false, true, 1, 100, false, tc, true);
+        }
         bad += StyleAndAntiAliasScenario(dir);
         // error behaviour: Render() without a model draws nothing (Renderer.cs:736-739)
         { Renderer r(0); r.rayTrace = true; r.SetRenderingSurface(4, 4, pixels.data()); r.Render(); }

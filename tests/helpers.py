@@ -137,3 +137,19 @@ def c1_spheres(count=16, seed=12345):
         argb = (255 << 24) + (int(cr * 255.0) << 16) + (int(cg * 255.0) << 8) + int(cb * 255.0)
         prims.append((0, argb, c + [r]))
     return prims
+
+
+def leaf_face_scene():
+    """The adversarial scene for the one documented difference between SR_MODE_REF_TREE and SR_MODE_BVH (include/softray.h): two hits
+    within 1e-10 of each other across a leaf face of the reference tree.  The root box is longest in z, so the tree (max 2 per leaf)
+    splits at z = 0.  T (red) straddles the split plane and crosses the rays x = 0 at z = 5e-11 -- inside the z < 0 leaf's box by the
+    reference's 1e-10 containment slack (AxisAlignedBox.cs:143-149, SpatialSubdivision.cs:652); T2 (green) lies entirely at z = 2e-11
+    (only in the z >= 0 leaf) and is NEARER.  A ray along +z from z < 0 visits the z < 0 leaf first, accepts T there and returns it
+    (SpatialSubdivision.cs:458-627); the global nearest hit is T2.  T3 only keeps the split from being rejected (:167-181)."""
+    e1, e2 = 5e-11, 2e-11
+    t = [(1, -1, e1 + 0.01), (-1, -1, e1 - 0.01), (0, 1.5, e1)]             # plane z - 0.01 x = e1, facing -z
+    t2 = [(1, -1, e2), (-1, -1, e2), (0, 1.5, e2)]
+    t3 = [(1.9, 1.5, -3.0), (1.5, 1.5, -3.0), (1.7, 1.9, -3.0)]
+    v9 = np.array([t, t2, t3], dtype=np.float64)
+    argb = np.array([0xFFFF0000, 0xFF00FF00, 0xFF0000FF], dtype=np.uint32)
+    return v9, argb, np.array([-2.0, -2.0, -4.0]), np.array([2.0, 2.0, 4.0])
