@@ -221,6 +221,121 @@ def committed_profile(PROFILE_DIR):
     return out
 
 
+# the reference's own published numbers: asserted throughput windows of its MSTest suite, AppVeyor build server, Release
+REFERENCE_WINDOWS = {
+    "ray_plane": (7.9, 10.8, "Mrays/s", "TriangleTests.cs:121-122"),
+    "ray_triangle": (7.9, 12.9, "Mrays/s", "TriangleTests.cs:159-160"),
+    "ray_sphere_from_inside": (4.9, 7.0, "Mrays/s", "TriangleTests.cs:200-201"),
+    "ray_sphere_mostly_from_outside": (3.9, 6.5, "Mrays/s", "TriangleTests.cs:240-241"),
+    "ray_sphere_randomly": (6.0, 9.5, "Mrays/s", "TriangleTests.cs:280-281"),
+    "ray_aabb": (2.9, 4.1, "Mrays/s", "TriangleTests.cs:320-321"),
+    "brute_force_1000_from_inside": (21.0, 29.0, "M ray-triangle/s", "SpatialSubdivisionTests.cs:158-159"),
+    "tree_1000_from_inside": (60.0, 82.0, "M ray-triangle-equivalents/s", "SpatialSubdivisionTests.cs:204-205"),
+    "tree_1000_mostly_from_outside": (25.0, 29.0, "M ray-triangle-equivalents/s", "SpatialSubdivisionTests.cs:248-249"),
+}
+
+
+def micro_benchmarks(args, dev):
+    """The reference's only published figures, like for like: its per-primitive and per-tree IntersectRay micro-loops
+    (TriangleTests.cs:100-345, SpatialSubdivisionTests.cs:148-282), with rays generated the way those tests generate them (System.Random;
+    the tree tests' rays continue the seeded triangle stream), DEVICE-resident in and out (sr_trace_rays_device: the reference times
+    IntersectRay, not a transfer), timed with HIP events on the launch stream.  Beside each: the reference's asserted window on its
+    authors' build server and the oracle (the C++ restatement) on this host's cores, one thread, like the reference's loop."""
+    g = sa.GpuScene(dev.index)
+    stream = torch.cuda.current_stream(dev)
+    n = args.micro_rays
+    rng = lambda seed, k, skip=0: sa.net_random_doubles(seed, k, skip)
+
+    def lerp3(u, lo, hi):                                             # MakeRandomVector(minX, maxX, minY, maxY, minZ, maxZ)
+        lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+        return u * (hi - lo) + lo
+
+    def rays_6(seed, count, skip=0):
+        return rng(seed, 6 * count, skip).reshape(count, 6)
+
+    empty = (np.zeros((0, 3, 3)), np.zeros(0, dtype=np.uint32), np.array([-1.0] * 3), np.array([1.0] * 3))
+    # name -> (model, tree parameters, extra geometry, target, (starts, dirs), units of work per ray)
+    u = rays_6(12345, n)
+    ones = np.ones(3)
+    cases = []
+    cases.append(("ray_plane", empty, None, [(1, 0xffffffff, [0, 0, -100, 1, 1, 1])], sa.TARGET_ROOT | sa.MODE_BRUTE,
+                  (u[:, :3] * ones, lerp3(u[:, 3:], [-1] * 3, [1] * 3)), 1))                      # Plane(forward * 100, (1, 1, 1)), :133-139
+    cases.append(("ray_triangle", empty, None, [(2, 0xffffffff, [0, 0, 0, 1, 0, 0, 0, 1, 0])], sa.TARGET_ROOT | sa.MODE_BRUTE,
+                  (u[:, :3] * ones, np.tile([0.0, 0.0, -1.0], (n, 1))), 1))                       # Triangle(origin, right, up), dir = forward, :171-178
+    cases.append(("ray_sphere_from_inside", empty, None, [(0, 0xffffffff, [0.5, 0.5, 0.5, 1.0])], sa.TARGET_ROOT | sa.MODE_BRUTE,
+                  (u[:, :3] * ones, lerp3(u[:, 3:], [-1] * 3, [1] * 3)), 1))                      # :211-219
+    so = lerp3(u[:, :3], [-10] * 3, [10] * 3)
+    cases.append(("ray_sphere_mostly_from_outside", empty, None, [(0, 0xffffffff, [0.5, 0.5, 0.5, 1.0])], sa.TARGET_ROOT | sa.MODE_BRUTE,
+                  (so, u[:, 3:] * ones - so), 1))                                                  # :251-259
+    cases.append(("ray_sphere_randomly", empty, None, [(0, 0xffffffff, [0.0, 0.0, 0.0, 1.0])], sa.TARGET_ROOT | sa.MODE_BRUTE,
+                  (lerp3(u[:, :3], [-2] * 3, [2] * 3), lerp3(u[:, 3:], [-1] * 3, [1] * 3)), 1))   # :291-298
+    cases.append(("ray_aabb", empty, None, [(4, 0xffffffff, [-0.5, -0.5, -0.5, 0.5, 0.5, 0.5])], sa.TARGET_ROOT | sa.MODE_BRUTE,
+                  (lerp3(u[:, :3], [-0.3, -0.3, 0.5], [0.3, 0.3, 1.0]), lerp3(u[:, 3:], [-0.5, -0.5, -1.0], [0.5, 0.5, -1.0])), 1))   # :331-337
+    # the seeded 1000-triangle soup (MakeRandomTriangles: space 100, extent 10, seed 12345); rays continue the SAME stream
+    tv9, targb = sa.make_random_triangles(1000, 12345, space=100.0, extent=10.0)
+    tbox = (np.array([0.0] * 3), np.array([110.0] * 3))                                           # GetBoundingBoxOfRandomTriangles
+    ut = rays_6(12345, n, skip=10 * 1000)
+    inside = (ut[:, :3] * 100.0, lerp3(ut[:, 3:], [-1] * 3, [1] * 3))                              # :181-183, :225-227
+    st_out = ut[:, :3] * 1000.0
+    outside = (st_out, ut[:, 3:] * 100.0 - st_out)                                                 # :269-271
+    soup = (tv9, targb) + tbox
+    cases.append(("brute_force_1000_from_inside", soup, None, [], sa.MODE_BRUTE, inside, 1000))
+    cases.append(("tree_1000_from_inside", soup, (10, 5), [], sa.MODE_REF_TREE, inside, 1000))
+    cases.append(("tree_1000_mostly_from_outside", soup, (10, 5), [], sa.MODE_REF_TREE, outside, 1000))
+    cases.append(("own_bvh_1000_from_inside", soup, "bvh", [], sa.MODE_BVH, inside, 1000))
+
+    from oracle import oracle_py as orc                              # cpu_baseline leg: the oracle timed beside the device
+    results = {}
+    hit = torch.zeros(n, dtype=torch.uint8, device=dev); frac = torch.zeros(n, dtype=torch.float64, device=dev)
+    pos = torch.zeros((n, 3), dtype=torch.float64, device=dev); nrm = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    col = torch.zeros(n, dtype=torch.int32, device=dev); tri = torch.zeros(n, dtype=torch.int32, device=dev)
+    for name, model, tree, extra, target, (starts, dirs), work in cases:
+        g.set_triangles(*model)
+        g.set_extra(extra)
+        if tree == "bvh":
+            g.build((sa.MODE_BVH,))
+        elif tree:
+            g.build((sa.MODE_REF_TREE,), tree[0], tree[1])
+        d_s = torch.from_numpy(np.ascontiguousarray(starts)).to(dev); d_d = torch.from_numpy(np.ascontiguousarray(dirs)).to(dev)
+        call = lambda: g.trace_device(target, n, d_s.data_ptr(), d_d.data_ptr(), hit.data_ptr(), frac.data_ptr(), pos.data_ptr(), nrm.data_ptr(),
+                                      col.data_ptr(), tri.data_ptr(), 0, stream.cuda_stream)
+        call(); torch.cuda.synchronize(dev)
+        best = float("inf")
+        for _ in range(5):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream); call(); b.record(stream); b.synchronize()
+            best = min(best, a.elapsed_time(b))
+        h = hit.cpu().numpy()
+        # CPU: the oracle, one thread, on a bounded sample of the same rays
+        o = orc.Scene()
+        o.set_triangles(*model)
+        o.set_extra(extra)
+        otarget = 2 if extra else {sa.MODE_BRUTE: 0, sa.MODE_REF_TREE: 1, sa.MODE_BVH: 3}[target & 0xff]
+        if tree and tree != "bvh":
+            assert o.build_tree(tree[0], tree[1]) == 0
+        elif tree == "bvh":
+            assert o.build_tree() == 0
+        m = min(n, 1000000 if work == 1 else 20000)
+        t0 = time.perf_counter()
+        ob = o.trace(otarget, starts[:m], dirs[:m])
+        cpu_s = time.perf_counter() - t0
+        ref = REFERENCE_WINDOWS.get(name)
+        results[name] = {
+            "rays": n, "hit_rate": float(h.mean()), "device_ms": best, "device_Mrays_per_s": n / (best * 1e-3) / 1e6,
+            "device_in_reference_units": n * work / (best * 1e-3) / 1e6,
+            "reference_window": {"min": ref[0], "max": ref[1], "unit": ref[2], "source": ref[3], "hardware": "AppVeyor build server, Release, one thread"} if ref else None,
+            "cpu_oracle": {"in_reference_units": m * work / cpu_s / 1e6, "rays": m, "seconds": cpu_s, "threads": 1,
+                           "note": "C++ restatement incl. the ctypes call and the result arrays"},
+            "first_rays_equal_oracle": bool(np.array_equal(h[:m], ob["hit"])) and bool(np.array_equal(frac[:m].cpu().numpy(), ob["ray_frac"])),
+        }
+    g.close()
+    return {"metric": "IntersectRay micro-benchmarks of the reference (BASELINE.md 1), device-resident rays", "unit": "see entries", "n_gpus": 1,
+            "data": "synthetic (System.Random seed 12345, generated as the reference's tests generate them)", "dtype": "f64",
+            "micro": results,
+            "note": "device_in_reference_units is in the unit of reference_window (ray-triangle products for the 1000-triangle cases, as the reference counts "
+                    "them); one lane per ray, FP64, bit-identical to the oracle on the compared prefix"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +366,11 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
     ap.add_argument("--no-verify", action="store_true", help="N > 1 verifies the gathered frame against a single-GPU render by default; this turns it off")
     ap.add_argument("--master-port", type=int, default=0, help="rendezvous port of the ranks a plain `--gpus N` run spawns (0 = pick a free one)")
+    ap.add_argument("--gather", default="torch", choices=["torch", "rccl"],
+                    help="N > 1: the strip gather inside the timed region -- torch.distributed.gather, or the library's own grouped ncclSend / ncclRecv "
+                         "(sr_rccl_render; with --in-library: sr_set_gather).  The other one is exercised once after the timed region either way")
+    ap.add_argument("--micro", action="store_true", help="instead of the frame benchmark: the reference's IntersectRay micro-benchmarks (BASELINE.md 1), device-resident")
+    ap.add_argument("--micro-rays", type=int, default=1 << 22)
     args = ap.parse_args()
 
     # ---- plain `python bench.py --gpus N` (no launcher): become the launcher.  BEFORE anything touches the GPU this process starts
@@ -285,6 +405,11 @@ def main():
     local_rank = local_rank % ndev            # (rehearsals with more ranks than GPUs share devices; the driver uses one rank per GPU)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.micro:
+        if world > 1 or args.gpus > 1:
+            raise SystemExit("--micro is a one-GPU measurement")
+        print(json.dumps(micro_benchmarks(args, dev)))
+        return
     if world > 1:
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -297,6 +422,8 @@ def main():
     if in_library:
         devices = [0] * args.gpus if args.same_device else [d % ndev for d in range(args.gpus)]
         g = sa.GpuScene(devices=devices)
+        if args.gather == "rccl":
+            g.set_gather(sa._lib.GATHER_RCCL)                       # grouped ncclSend / ncclRecv between the parts (needs distinct devices)
     else:
         g = sa.GpuScene(local_rank)
     g.set_triangles(v9, argb, bmin, bmax)
@@ -330,7 +457,44 @@ def main():
     pending = [None, None]                                           # gather handles of the two buffer sets
     state = {"k": 0, "readback": True}
 
+    full_frame = make_frame(args)                                    # the whole frame: sr_rccl_render deals the strips out itself
+    native = {"ready": False}
+
+    def native_init():
+        """The library's own communicator (ncclCommInitRank through sr_rccl_init): rank 0 makes the id, the 128 bytes travel through
+        torch.distributed's store -- plumbing; the pixels never touch PyTorch on this path."""
+        if native["ready"]:
+            return
+        box = [sa.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        g.rccl_init(box[0], world, rank)
+        native["ready"] = True
+
+    use_native = world > 1 and args.gather == "rccl"
+    if use_native:
+        if args.strip_rows != 16:
+            raise SystemExit("--gather rccl uses the library's 16-row strips")
+        native_init()
+        full_dev = [torch.zeros(full_px, dtype=torch.int32, device=dev) for _ in range(2)] if rank == 0 else [None, None]
+
+    def step_native():
+        k = state["k"] % 2
+        state["k"] += 1
+        if rank == 0 and copied_once[k]:
+            stream.wait_event(copied[k])                             # surface k is free once its last read-back has finished
+        g.rccl_render(full_frame, full_dev[k].data_ptr() if rank == 0 else 0, stream.cuda_stream)
+        if rank == 0:
+            rendered[k].record(stream)
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(rendered[k])
+                if state["readback"]:
+                    host[k].copy_(full_dev[k], non_blocking=True)
+                copied[k].record(copy_stream)
+            copied_once[k] = True
+
     def step():
+        if use_native:
+            return step_native()
         k = state["k"] % 2
         state["k"] += 1
         if args.static_shadows:
@@ -409,7 +573,8 @@ def main():
                                        args.tris, args.extent, args.res, args.res, args.spp * args.spp, args.shadows, args.depth),
                        "trace_mode": args.mode,
                        "parallelism": ("rows x%d (interleaved %d-row strips, %s)" % (
-                           n_gpus, args.strip_rows, "one process, sr_create_multi" if in_library else "one process per GPU + RCCL gather")) if n_gpus > 1 else "one GPU",
+                           n_gpus, args.strip_rows, ("one process, sr_create_multi, gather: %s" % ("grouped ncclSend/ncclRecv" if args.gather == "rccl" else "peer copies")) if in_library
+                           else ("one process per GPU + %s" % ("the library's grouped ncclSend/ncclRecv (sr_rccl_render)" if use_native else "torch.distributed.gather over RCCL")))) if n_gpus > 1 else "one GPU",
                        "readback": "every frame copied to pinned host memory inside the timed region (the copy of frame k overlaps frame k+1)"},
             "build_s": build_s,
         }
@@ -454,9 +619,56 @@ def main():
         gather_ms = min(wall(gather_only) for _ in range(reps))
         deint_ms = min(wall(lambda: sg[0].finish()) for _ in range(reps))
         rb_ms = min(wall((lambda: host[0].copy_(surfaces[0].view(-1))) if rank == 0 else (lambda: None)) for _ in range(reps))
+        # ---- the gather that was NOT timed, once, against the frame that arrived: hardware evidence for both paths from one run.  Guarded
+        #      by a watchdog: a collective that hangs must not cost the line above it ----
+        other = {"path": "torch.distributed.gather" if use_native else "sr_rccl_render (grouped ncclSend / ncclRecv, no PyTorch in the data path)"}
+        if dist.get_backend() == "nccl" and args.strip_rows == 16:
+            import threading
+
+            def other_gather():
+                try:
+                    torch.cuda.set_device(dev)                        # (a new thread starts on device 0)
+                    if use_native:
+                        g.render_device(frame, sg[0].local.data_ptr(), stream.cuda_stream)
+                        t = time.perf_counter()
+                        sg[0].exchange()
+                        torch.cuda.synchronize(dev)
+                        other["ms"] = (time.perf_counter() - t) * 1e3
+                        got = sg[0].full.view(-1) if rank == 0 else None
+                    else:
+                        native_init()
+                        got = torch.zeros(full_px, dtype=torch.int32, device=dev) if rank == 0 else None
+                        g.rccl_render(full_frame, got.data_ptr() if rank == 0 else 0, stream.cuda_stream)     # (first call: communicator warm-up)
+                        torch.cuda.synchronize(dev)
+                        dist.barrier()
+                        t = time.perf_counter()
+                        g.rccl_render(full_frame, got.data_ptr() if rank == 0 else 0, stream.cuda_stream)
+                        torch.cuda.synchronize(dev)
+                        other["ms"] = (time.perf_counter() - t) * 1e3
+                    if rank == 0:
+                        other["frame_equal"] = bool(np.array_equal(got.cpu().numpy(), last_host_frame))
+                    other["ok"] = True
+                except Exception as e:                                # reported, never fatal for the line
+                    other["ok"] = False
+                    other["error"] = repr(e)[:300]
+
+            th = threading.Thread(target=other_gather, daemon=True)
+            th.start()
+            th.join(120.0)
+            if th.is_alive():
+                other["ok"] = False
+                other["error"] = "no completion within 120 s"
+                if rank == 0:
+                    out["multi_gpu_other_gather"] = other
+                    print(json.dumps(out), flush=True)
+                os._exit(0 if rank != 0 else 0)
+        else:
+            other["skipped"] = "needs the nccl backend and 16-row strips"
         if rank == 0:
+            out["multi_gpu_other_gather"] = other
             out["multi_gpu"] = {
                 "backend": dist.get_backend(), "rccl_ranks": dist.get_world_size() if dist.get_backend() == "nccl" else None,
+                "timed_gather": "sr_rccl_render" if use_native else "torch.distributed.gather",
                 "world_size": dist.get_world_size(), "visible_devices": ndev,
                 "distinct_devices": len({(e["device"]) for e in everyone}),
                 "ranks": everyone,

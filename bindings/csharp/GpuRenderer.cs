@@ -70,6 +70,8 @@ namespace Engine3D.Hip
         const string Lib = "softray_hip";
         [DllImport(Lib)] public static extern int sr_create(int device, out IntPtr scene);
         [DllImport(Lib)] public static extern int sr_create_multi([In] int[] devices, int n, out IntPtr scene);
+        [DllImport(Lib)] public static extern int sr_set_gather(IntPtr scene, int kind);                  // 0 peer copies (default), 1 grouped ncclSend / ncclRecv
+        [DllImport(Lib)] public static extern int sr_render_device(IntPtr scene, ref SrFrame frame, IntPtr dPixels, IntPtr hipStream, IntPtr dStats);
         [DllImport(Lib)] public static extern void sr_destroy(IntPtr scene);
         [DllImport(Lib)] public static extern int sr_set_triangles(IntPtr scene, double[] v9, uint[] argb, long n, double[] boxMin, double[] boxMax);
         [DllImport(Lib)] public static extern int sr_set_extra_geometry(IntPtr scene, [In] SrPrim[] prims, int n);
@@ -85,7 +87,7 @@ namespace Engine3D.Hip
         public static string LastError() { return Marshal.PtrToStringAnsi(sr_last_error()); }
 
         public const int SR_ERR_INVALID_ARG = -1, SR_ERR_OUT_OF_RANGE = -2, SR_ERR_NO_MODEL = -3, SR_ERR_FORMAT = -8;
-        public const int AbiVersion = 4;
+        public const int AbiVersion = 5;
 
         /// <param name="renderCall">true only for sr_render: Render() without a model draws nothing and returns (Renderer.cs:736-739)</param>
         public static void Check(int rc, bool renderCall = false)
@@ -106,6 +108,7 @@ namespace Engine3D.Hip
     public sealed class SoftrayHip : IDisposable
     {
         public const uint F_SHADING = 1, F_SHADOWS = 2, F_FOCAL_BLUR = 4, F_POINT_LIGHT = 8, F_SPECULAR = 16, F_STATIC_SHADOWS = 32;
+        const uint F_PRIMARY_STATS_ONLY = 1u << 12;     // Num* count primary rays (Renderer.cs:1916-1923): no counting in the shadow stage
         public const int MODE_REF_TREE = 0, MODE_BRUTE = 1, MODE_BVH = 2;
         /// How NumGeometryTests / NumNodeVisits / NumLeafNodeVisits (Renderer.cs:476-504) are answered -- an explicit choice of the
         /// constructor, because they are the literal reference-tree traversal's counters and the fast path does not walk that tree.
@@ -118,7 +121,7 @@ namespace Engine3D.Hip
         /// include/softray.h SR_MODE_BVH; obj.3DS at 1024^2: 0.36 ms literal, 0.17 ms on the own BVH).
         public enum TraversalCounters { Auto, Literal, Off }
         public readonly TraversalCounters Counters;
-        public int OwnBvhThreshold = 20000;
+        public int OwnBvhThreshold = 2000;
         /// Did the last Render() produce the three traversal counters?  (false: it ran on the own BVH)
         public bool CountersAvailable { get; private set; } = true;
         IntPtr scene;
@@ -140,11 +143,15 @@ namespace Engine3D.Hip
 
         /// <summary>A whole node from this one process: the frame's rows are split into interleaved 16-row strips over
         /// `devices` inside the library and copied straight into the caller's pixels (sr_create_multi).</summary>
-        public SoftrayHip(int[] devices, TraversalCounters counters = TraversalCounters.Auto)
+        /// gatherOverRccl: frames that STAY on the first device (sr_render_device: a host that post-processes or displays from HBM)
+        /// are gathered with one grouped ncclSend / ncclRecv over xGMI (sr_set_gather, include/softray.h) instead of peer copies;
+        /// Render() into a managed int[] copies every device's strips over its own PCIe link either way.
+        public SoftrayHip(int[] devices, TraversalCounters counters = TraversalCounters.Auto, bool gatherOverRccl = false)
         {
             Counters = counters;
             if (Native.sr_abi_version() != Native.AbiVersion) throw new InvalidOperationException("libsoftray_hip: ABI version mismatch");
             Native.Check(Native.sr_create_multi(devices, devices.Length, out scene));
+            if (gatherOverRccl) Native.Check(Native.sr_set_gather(scene, 1));
         }
 
         /// PreCalculate() (Renderer.cs:673-699): MakeRayTracableGeometry_simple (:1452-1469) flattened, then the structure for
@@ -206,7 +213,7 @@ namespace Engine3D.Hip
             {
                 var prim = new SrPrim { p = new double[9] };
                 IRayIntersectable g = extras[i];
-                var sphere = g as Sphere; var plane = g as Plane; var tri = g as Raytrace.Triangle;
+                var sphere = g as Sphere; var plane = g as Plane; var tri = g as Raytrace.Triangle; var box = g as AxisAlignedBox;
                 if (sphere != null)
                 {
                     prim.kind = 0; prim.argb = sphere.PackedColor;                                    // Color.ToARGB(), Sphere.cs:51-55
@@ -224,7 +231,12 @@ namespace Engine3D.Hip
                     prim.p[3] = tri.Vertex2.x; prim.p[4] = tri.Vertex2.y; prim.p[5] = tri.Vertex2.z;
                     prim.p[6] = tri.Vertex3.x; prim.p[7] = tri.Vertex3.y; prim.p[8] = tri.Vertex3.z;
                 }
-                else throw new NotSupportedException("ExtraGeometryToRaytrace holds a " + g.GetType().Name + ": only Sphere, Plane and Triangle have a device form");
+                else if (box != null)
+                {
+                    prim.kind = 4; prim.argb = 0xffffffffu;                                           // six Color.White planes (AxisAlignedBox.cs:22-27, Plane.cs:28)
+                    prim.p[0] = box.Min.x; prim.p[1] = box.Min.y; prim.p[2] = box.Min.z; prim.p[3] = box.Max.x; prim.p[4] = box.Max.y; prim.p[5] = box.Max.z;
+                }
+                else throw new NotSupportedException("ExtraGeometryToRaytrace holds a " + g.GetType().Name + ": only Sphere, Plane, Triangle and AxisAlignedBox have a device form");
                 prims[i] = prim;
             }
             if (n == 0) prims[0].p = new double[9];
@@ -258,7 +270,7 @@ namespace Engine3D.Hip
                 frameReady = true;
             }
             frame.width = width; frame.height = height; frame.start_row = startRow; frame.end_row = endRow; frame.sub_pixel_res = subPixelRes;
-            frame.background_argb = backgroundColor; frame.flags = flags; frame.random_seed = randomSeed; frame.shadow_samples = 0; frame.trace_mode = mode;
+            frame.background_argb = backgroundColor; frame.flags = flags | F_PRIMARY_STATS_ONLY; frame.random_seed = randomSeed; frame.shadow_samples = 0; frame.trace_mode = mode;
             frame.concurrency = concurrency;                                 // rayTraceConcurrency: fill order of the static shadow cache
             frame.position_z = instance.Position.z; frame.fov_depth = fieldOfViewDepth; frame.focal_depth = focalDepth;
             frame.focal_blur_strength = focalBlurStrength; frame.ambient = ambient; frame.shininess = shininess;

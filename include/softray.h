@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define SR_ABI_VERSION 4
+#define SR_ABI_VERSION 5
 #define SR_STATS_COUNT 24   /* entries of the ray-statistics array (sr_last_ray_stats, sr_render_device's d_stats) */
 
 enum {
@@ -75,11 +75,15 @@ enum {
     SR_F_PER_LANE_SHADOWS = 1u << 9, /* library option: trace shadow samples one lane per hit point (k_shadow)
                                      instead of one wavefront per hit point with a shared shaft walk
                                      (k_shadow_packet).  Pixels are identical; cross-check                  */
-    SR_F_LITERAL_SECONDARY = 1u << 11 /* library option: a SR_MODE_REF_TREE frame traces its SHADOW rays through the reference tree
+    SR_F_LITERAL_SECONDARY = 1u << 11, /* library option: a SR_MODE_REF_TREE frame traces its SHADOW rays through the reference tree
                                      too.  By default (own BVH built, point light, <= 1024 samples) they are answered on the
                                      library's BVH (shaft path): "is there a hit with rayFrac <= 1.0" has the same answer, and the
                                      four statistics of sr_render count the primary rays, which keep the literal traversal either
                                      way.  With the flag the secondary counters of sr_last_ray_stats are the reference tree's  */
+    SR_F_PRIMARY_STATS_ONLY = 1u << 12 /* library option: with `stats`, count the primary rays only -- the four statistics of sr_render
+                                     (NumRaysFired, NumGeometryTests, NumNodeVisits, NumLeafNodeVisits).  The shadow stage then runs
+                                     its uncounted kernels (counting costs atomics per hit point: obj.3DS 1024^2 + shadows 2.3 -> 1.1 ms)
+                                     and entries 4.. of sr_last_ray_stats read 0.  What the hosts' Render() sets             */
 };
 
 /* how the model's triangles are intersected */
@@ -101,7 +105,11 @@ typedef struct {
                            2 Triangle {v1, v2, v3}                Raytrace/Triangle.cs:29-57
                            3 Plane as the object holds it {Plane.Normal xyz (unit), Plane.DistanceToOrigin}
                              (Plane.cs:40-62): what a host passes for an EXISTING Plane -- kind 1 would
-                             normalise and project again and could differ in the last bit              */
+                             normalise and project again and could differ in the last bit
+                           4 AxisAlignedBox {min xyz, max xyz} (AxisAlignedBox.cs:15-28, IntersectRay :60-95):
+                             the nearest of its six one-sided planes' hits that lies on the box; the hit
+                             carries the plane's colour (Color.White, Plane.cs:28): argb is not read;
+                             NumRayTests = 6                                                            */
     uint32_t argb;      /* Color.ToARGB() of the primitive's Color                                      */
     double   p[9];
 } sr_prim;
@@ -243,12 +251,23 @@ int  sr_trace_rays(sr_scene*, int32_t target, int64_t n, const double* starts, c
                    uint8_t* hit, double* ray_frac, double* pos, double* normal, uint32_t* color,
                    int32_t* tri_index, int32_t* counters);
 
+/* The same with every array in DEVICE memory on the scene's device, enqueued on `hip_stream` without a host synchronisation: what a
+ * throughput measurement of the reference's per-primitive / per-tree micro-benchmarks needs (TriangleTests.cs:100-330,
+ * SpatialSubdivisionTests.cs:140-260 time IntersectRay alone, not a transfer).  Outputs may be NULL. */
+int  sr_trace_rays_device(sr_scene*, int32_t target, int64_t n, const double* d_starts, const double* d_dirs,
+                          uint8_t* d_hit, double* d_ray_frac, double* d_pos, double* d_normal, uint32_t* d_color,
+                          int32_t* d_tri_index, int32_t* d_counters, void* hip_stream);
+
 /* ShadingMethod.IntersectRay's colour step in batch (ShadingMethod.cs:36-68 -> CalcLighting :110-177): for n recorded
  * intersections out[i] = ModulatePackedColor(color[i], (byte)(255 * intensity)) with the frame's transform and lights (only the
  * matrices, position_z, fov_depth, lights, ambient, shininess and the POINT_LIGHT / SPECULAR flags of `frame` are read).
  * Host arrays.  The decorator's arithmetic on its own -- Math.Pow included -- without a traversal in front of it. */
 int  sr_shade_points(sr_scene*, const sr_frame* frame, int64_t n, const double* pos, const double* normal, const uint32_t* color,
                      uint32_t* out);
+
+/* n NextDouble() of new System.Random(seed) after `skip` samples have been drawn (Next() and NextDouble() consume one each):
+ * hosts regenerate the reference's seeded test inputs with it (rays that continue the triangle stream, SpatialSubdivisionTests.cs:141,225) */
+void sr_net_random_doubles(int32_t seed, int64_t skip, int64_t n, double* out);
 
 /* Instance.InitRender matrices (Instance.cs:134-135, Matrix.cs:74-169): T = Trans(P)*Roll*Pitch*Yaw,
  * T^-1 = Yaw(-)*Pitch(-)*Roll(-)*Trans(-P); rows 0..2, row-major 3x4. */
@@ -292,6 +311,33 @@ int  sr_last_ray_stats(const sr_scene*, uint64_t out[SR_STATS_COUNT]);
  * the device regenerate identical inputs. */
 void sr_make_random_triangles(int32_t seed, int64_t n, double space, double extent, double origin, int32_t opaque,
                               double* v9, uint32_t* argb);
+
+/* ---- the row-strip gather over RCCL / xGMI, native (replaces the TPL fan-out of Renderer.cs:1655-1680 across GPUs) ----
+ * The frame's rows are dealt out in interleaved 16-row strips (strip s belongs to rank s % world); every rank renders its strips
+ * into a compact buffer and ONE exchange step brings them to rank 0: grouped ncclSend (ranks 1..) / ncclRecv (rank 0) of
+ * rows_r x W x 4 bytes each, followed on rank 0 by the row de-interleave (strided device copies) into the full surface.  No
+ * reduction, no RNG: the frame does not depend on the split.  librccl is bound with dlopen at first use (a single-GPU host never
+ * loads it; a process that already holds an RCCL -- PyTorch's -- keeps using that one); SR_ERR_UNSUPPORTED when it is absent.
+ *
+ * One process per GPU (no PyTorch needed): rank 0 calls sr_rccl_unique_id and hands the 128 bytes to the other ranks by whatever
+ * means the host has (a file, a socket, MPI, a torch store); every rank calls sr_rccl_init(scene, id, world, rank) on its own
+ * single-device scene (ncclCommInitRank on the scene's device), then per frame sr_rccl_render(scene, frame, d_full, stream):
+ * renders this rank's strips of `frame` (strip_count must be 0: the split is the library's) and gathers; d_full (device memory,
+ * W*H int32) is only written on rank 0 and may be NULL elsewhere.  sr_rccl_gather is the exchange step on its own, for a host
+ * that rendered its strips itself (sr_frame.strip_rows = 16, strip_count = world, strip_index = rank) into d_strips.  Everything
+ * is enqueued on `hip_stream`; consecutive frames of a scene must use the same stream.
+ *
+ * One process, several devices (sr_create_multi): sr_set_gather(scene, SR_GATHER_RCCL) makes sr_render_device gather the parts'
+ * strips with the same grouped send / receive (ncclCommInitAll over the scene's devices, which must be distinct) instead of peer
+ * copies -- SR_GATHER_COPY, the default: hipMemcpy2DAsync peer-to-peer where the devices allow it, pinned host staging where not.
+ * sr_render (host surface) copies every part's strips over its own PCIe link either way. */
+#define SR_RCCL_ID_BYTES 128
+enum { SR_GATHER_COPY = 0, SR_GATHER_RCCL = 1 };
+int  sr_rccl_unique_id(uint8_t out[SR_RCCL_ID_BYTES]);
+int  sr_rccl_init(sr_scene*, const uint8_t id[SR_RCCL_ID_BYTES], int32_t world, int32_t rank);
+int  sr_rccl_render(sr_scene*, const sr_frame*, void* d_full, void* hip_stream);
+int  sr_rccl_gather(sr_scene*, const sr_frame*, const void* d_strips, void* d_full, void* hip_stream);
+int  sr_set_gather(sr_scene* multi_device_scene, int32_t kind);
 
 /* ---- surface passes that Renderer.Render() runs after the raytrace (Engine3D/Renderer.cs:765-767) ----
  * sr_post_process[_device]  = PostProcessImage's per-pixel colour functions (Renderer.cs:819-865, Surface.ApplyColorFunc

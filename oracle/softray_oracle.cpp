@@ -308,6 +308,20 @@ struct AxisAlignedBox {
                min.y - epsilon < pos.y && pos.y < max.y + epsilon &&
                min.z - epsilon < pos.z && pos.z < max.z + epsilon;
     }
+    /* AxisAlignedBox.IntersectRay, :60-95: the nearest of the six one-sided planes' hits that lies on the box (ContainsPoint) */
+    bool IntersectRay(Vec start, Vec dir, Hit& info) const {
+        Hit closest;
+        closest.rayFrac = DBL_MAX;
+        for (int i = 0; i < 6; i++) {
+            Hit curr;
+            if (planes[i].IntersectRay(start, dir, curr) && curr.rayFrac < closest.rayFrac) {
+                if (ContainsPoint(curr.pos)) closest = curr;
+            }
+        }
+        if (closest.rayFrac == DBL_MAX) return false;
+        info = closest;
+        return true;
+    }
     /* :111-141 */
     bool IntersectLineSegment(Vec start, Vec end, Vec& posOut) const {
         double closest = DBL_MAX;
@@ -603,6 +617,7 @@ struct orc_scene {
     std::vector<Sphere> spheres;         /* parallel storage, indexed through extraIdx */
     std::vector<Plane> planes;
     std::vector<Triangle> extraTris;
+    std::vector<AxisAlignedBox> extraBoxes;
     std::vector<int> extraIdx;
     std::vector<uint8_t> staticCache;    /* ShadowMethod's Texture3DCache<byte>(128): empty until the first static frame */
 };
@@ -667,6 +682,7 @@ bool RootIntersect(const orc_scene& s, int mode, Vec start, Vec dir, Hit& out, C
         switch (s.extra[i].kind) {
             case 0: ok = s.spheres[s.extraIdx[i]].IntersectRay(start, dir, h); break;
             case 1: ok = s.planes[s.extraIdx[i]].IntersectRay(start, dir, h); break;
+            case 4: ok = s.extraBoxes[s.extraIdx[i]].IntersectRay(start, dir, h); c.geomTests += 5; break;   /* NumRayTests = 6 planes, AxisAlignedBox.cs:70 */
             default: ok = s.extraTris[s.extraIdx[i]].IntersectRay(start, dir, h); break;
         }
         if (ok && h.rayFrac < closest.rayFrac) closest = h;
@@ -936,7 +952,7 @@ int orc_scene_set_triangles(orc_scene* s, const double* v9, const uint32_t* argb
 
 int orc_scene_set_extra(orc_scene* s, const orc_prim* prims, int32_t n) {
     s->extra.assign(prims, prims + n);
-    s->spheres.clear(); s->planes.clear(); s->extraTris.clear(); s->extraIdx.clear();
+    s->spheres.clear(); s->planes.clear(); s->extraTris.clear(); s->extraBoxes.clear(); s->extraIdx.clear();
     for (int i = 0; i < n; i++) {
         const orc_prim& p = prims[i];
         switch (p.kind) {
@@ -954,6 +970,11 @@ int orc_scene_set_extra(orc_scene* s, const orc_prim* prims, int32_t n) {
             case 2:
                 s->extraIdx.push_back((int)s->extraTris.size());
                 s->extraTris.emplace_back(V(p.p[0], p.p[1], p.p[2]), V(p.p[3], p.p[4], p.p[5]), V(p.p[6], p.p[7], p.p[8]), p.argb);
+                break;
+            case 4:                                              /* AxisAlignedBox(min, max): its planes are Color.White (Plane.cs:28) */
+                if (!(p.p[0] < p.p[3] && p.p[1] < p.p[4] && p.p[2] < p.p[5])) return -1;   /* Contract.Requires, AxisAlignedBox.cs:17-19 */
+                s->extraIdx.push_back((int)s->extraBoxes.size());
+                s->extraBoxes.emplace_back(V(p.p[0], p.p[1], p.p[2]), V(p.p[3], p.p[4], p.p[5]));
                 break;
             default: return -1;
         }

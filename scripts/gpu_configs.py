@@ -55,16 +55,16 @@ for name, counters in (("TraversalCounters.Auto = the default: literal reference
     r.rayTraceShadows = True
     dt = timed(r, 5)
     out.append({"config": "C2 + 100-sample soft shadows, %s" % name, "ms": dt * 1e3, "Mrays_s": 1024 * 1024 / dt / 1e6})
-# the Auto threshold: a 19 999-triangle soup on the literal tree (Auto) against the own BVH (Off), 1024^2
+# the Auto threshold: a 1 999-triangle soup on the literal tree (Auto) against the own BVH (Off), 1024^2
 from softray_amd.renderer import Model
-v9s, argbs, bmins, bmaxs = sa.unit_cube_scene(19999)
+v9s, argbs, bmins, bmaxs = sa.unit_cube_scene(1999)
 for name, counters in (("Auto (literal tree + counters)", TraversalCounters.Auto), ("Off (own BVH)", TraversalCounters.Off)):
     r, px = setup(1024, 1.5, model=Model.FromTriangles(v9s, argbs, bmins, bmaxs), counters=counters)
     dt = timed(r, 10)
-    out.append({"config": "19 999 random triangles, 1024x1024, shading, %s" % name, "ms": dt * 1e3, "Mrays_s": 1024 * 1024 / dt / 1e6})
+    out.append({"config": "1 999 random triangles, 1024x1024, shading, %s" % name, "ms": dt * 1e3, "Mrays_s": 1024 * 1024 / dt / 1e6})
     r.rayTraceShadows = True
     dt = timed(r, 5)
-    out.append({"config": "19 999 random triangles + 100-sample soft shadows, %s" % name, "ms": dt * 1e3, "Mrays_s": 1024 * 1024 / dt / 1e6})
+    out.append({"config": "1 999 random triangles + 100-sample soft shadows, %s" % name, "ms": dt * 1e3, "Mrays_s": 1024 * 1024 / dt / 1e6})
 # C3: 1M random triangles + BVH, 2048^2, shading + shadows
 from softray_amd.renderer import Model
 v9, argb, bmin, bmax = sa.unit_cube_scene(1000000)

@@ -8,8 +8,8 @@ from . import _lib
 from ._lib import (F_FOCAL_BLUR, F_POINT_LIGHT, F_SHADING, F_SHADOWS, F_SPECULAR, F_STATIC_SHADOWS, MODE_BRUTE, MODE_BVH,
                    MODE_REF_TREE, TARGET_ROOT, Frame)
 from .scene import (GpuScene, SoftrayError, area_light_offsets, default_fov_depth, instance_matrices,
-                    make_random_triangles, unit_cube_scene)
+                    make_random_triangles, net_random_doubles, rccl_unique_id, unit_cube_scene)
 
-__all__ = ["GpuScene", "SoftrayError", "Frame", "make_random_triangles", "unit_cube_scene", "instance_matrices", "default_fov_depth", "area_light_offsets",
+__all__ = ["GpuScene", "SoftrayError", "Frame", "make_random_triangles", "net_random_doubles", "rccl_unique_id", "unit_cube_scene", "instance_matrices", "default_fov_depth", "area_light_offsets",
            "MODE_REF_TREE", "MODE_BRUTE", "MODE_BVH", "TARGET_ROOT", "F_SHADING", "F_SHADOWS", "F_STATIC_SHADOWS", "F_FOCAL_BLUR",
            "F_POINT_LIGHT", "F_SPECULAR", "_lib"]

@@ -19,6 +19,7 @@ F_SINGLE_KERNEL = 1 << 8
 F_PER_LANE_SHADOWS = 1 << 9
 F_NO_SPLIT = 1 << 10
 F_LITERAL_SECONDARY = 1 << 11
+F_PRIMARY_STATS_ONLY = 1 << 12
 MODE_REF_TREE, MODE_BRUTE, MODE_BVH = 0, 1, 2
 TARGET_ROOT = 0x100
 BUILD_ON_DEVICE = 0x100
@@ -33,7 +34,11 @@ SYMBOLS = [
     "sr_reset_kernel_times", "sr_kernel_times", "sr_last_ray_stats", "sr_make_random_triangles", "sr_debug_counters", "sr_last_error", "sr_abi_version",
     "sr_post_process", "sr_post_process_device", "sr_anti_alias", "sr_anti_alias_device", "sr_reset_shadow_cache",
     "sr_debug_set", "sr_bvh_stats", "sr_bvh_digest", "sr_wide_tree_stats", "sr_create_multi", "sr_device_count", "sr_shade_points",
+    "sr_trace_rays_device", "sr_rccl_unique_id", "sr_rccl_init", "sr_rccl_render", "sr_rccl_gather", "sr_set_gather",
+    "sr_net_random_doubles",
 ]
+GATHER_COPY, GATHER_RCCL = 0, 1
+RCCL_ID_BYTES = 128
 # sr_debug_set keys (include/softray.h)
 (DBG_BAND_SAMPLES, DBG_ROUND_CAP0, DBG_ROUND_CAP1, DBG_SPLIT, DBG_FB_RAY_CAP, DBG_BVH_LEAF, DBG_KERNEL_SWITCH,
  DBG_KERNEL_TIMING, DBG_EXACT_SHADOW_TESTS, DBG_PER_LANE_SHAFT, DBG_PER_LANE_PRIMARY, DBG_ROUND2_NODES, DBG_BUILD_THREADS,
@@ -136,6 +141,13 @@ def lib():
     L.sr_create_multi.restype = i32; L.sr_create_multi.argtypes = [vp, i32, C.POINTER(vp)]
     L.sr_device_count.restype = i32; L.sr_device_count.argtypes = [vp]
     L.sr_shade_points.restype = i32; L.sr_shade_points.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.sr_trace_rays_device.restype = i32; L.sr_trace_rays_device.argtypes = [vp, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.sr_rccl_unique_id.restype = i32; L.sr_rccl_unique_id.argtypes = [vp]
+    L.sr_rccl_init.restype = i32; L.sr_rccl_init.argtypes = [vp, vp, i32, i32]
+    L.sr_rccl_render.restype = i32; L.sr_rccl_render.argtypes = [vp, vp, vp, vp]
+    L.sr_rccl_gather.restype = i32; L.sr_rccl_gather.argtypes = [vp, vp, vp, vp, vp]
+    L.sr_set_gather.restype = i32; L.sr_set_gather.argtypes = [vp, i32]
+    L.sr_net_random_doubles.restype = None; L.sr_net_random_doubles.argtypes = [i32, i64, i64, vp]
     L.sr_last_error.restype = C.c_char_p; L.sr_last_error.argtypes = []
     L.sr_abi_version.restype = i32; L.sr_abi_version.argtypes = []
     _lib = L

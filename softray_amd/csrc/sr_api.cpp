@@ -17,6 +17,7 @@
 
 #include "sr_device.h"
 #include "sr_host.h"
+#include "sr_rccl.h"
 
 namespace {
 
@@ -34,6 +35,16 @@ int hip_fail(hipError_t e, const char* what) {
     do {                                                     \
         hipError_t e__ = (call);                             \
         if (e__ != hipSuccess) return hip_fail(e__, #call);  \
+    } while (0)
+
+int rccl_fail(const sr::RcclApi* api, int rc, const char* what) {
+    g_err = std::string(what) + ": " + (api && api->GetErrorString ? api->GetErrorString(rc) : "RCCL error") + " (" + std::to_string(rc) + ")";
+    return SR_ERR_HIP;
+}
+#define SR_RCCL(api, call)                                        \
+    do {                                                          \
+        int r__ = (call);                                         \
+        if (r__ != 0) return rccl_fail(api, r__, #call);          \
     } while (0)
 
 // growable device buffer
@@ -135,6 +146,13 @@ struct sr_scene {
     } scratch[kMaxSplit];
     hipEvent_t fork = nullptr;
     hipEvent_t multi_done = nullptr;     // (part of a multi-device scene) this part's strips of the current frame are rendered
+    // RCCL strip gather: one communicator per process-per-GPU scene (sr_rccl_init), or one per part of a multi-device
+    // scene (sr_set_gather(SR_GATHER_RCCL): ncclCommInitAll); rank 0 / the first part receives into d_gather (compact, rank after rank)
+    sr::RcclComm comm = nullptr;
+    int rccl_world = 0, rccl_rank = -1;
+    std::vector<sr::RcclComm> comms;
+    int gather_kind = 0;
+    DBuf d_gather;
     // the blocking calls (sr_render) never use the null stream: frames are enqueued on io_stream, their way back to the host runs on
     // copy_stream band by band (an event per row band: a band is copied while the next ones render)
     hipStream_t io_stream = nullptr, copy_stream = nullptr;
@@ -716,6 +734,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.per_lane_primary = s->dbg[SR_DBG_PER_LANE_PRIMARY] > 0;
         P.bvh2_packets = s->dbg[SR_DBG_BVH2_PACKETS] > 0;
         P.shadows_on_bvh = shadows_on_bvh;
+        P.primary_stats_only = (f->flags & SR_F_PRIMARY_STATS_ONLY) != 0;
         P.round2_node_budget = s->dbg[SR_DBG_ROUND2_NODES] >= 0 ? (int32_t)std::min<int64_t>(s->dbg[SR_DBG_ROUND2_NODES], 1 << 30) : 0;
         P.stats = d_stats;
         P.stream = bs;
@@ -892,7 +911,13 @@ int32_t sr_device_count(const sr_scene* s) { return !s ? 0 : (s->parts.empty() ?
 void sr_destroy(sr_scene* s) {
     if (!s) return;
     if (!s->parts.empty()) {
+        if (!s->comms.empty()) {
+            const sr::RcclApi* api = sr::rccl_api(nullptr);
+            for (size_t g = 0; api && g < s->comms.size(); ++g)
+                if (s->comms[g] && use_device(s->parts[g]) == SR_OK) (void)api->CommDestroy(s->comms[g]);
+        }
         if (s->multi_done && use_device(s->parts[0]) == SR_OK) (void)hipEventDestroy(s->multi_done);
+        if (use_device(s->parts[0]) == SR_OK) s->d_gather.release();
         for (sr_scene* q : s->parts) sr_destroy(q);
         delete s;
         return;
@@ -913,6 +938,8 @@ void sr_destroy(sr_scene* s) {
         if (s->pre_used) (void)hipEventDestroy(s->pre_used);
         if (s->multi_done) (void)hipEventDestroy(s->multi_done);
         for (DBuf& b : s->d_io) b.release();
+        s->d_gather.release();
+        if (s->comm) { const sr::RcclApi* api = sr::rccl_api(nullptr); if (api) (void)api->CommDestroy(s->comm); s->comm = nullptr; }
         for (int k = 0; k < sr::K_COUNT; ++k)
             for (hipEvent_t e : s->ev[k]) (void)hipEventDestroy(e);
     }
@@ -977,6 +1004,10 @@ int sr_set_extra_geometry(sr_scene* s, const sr_prim* prims, int32_t n) {
                 recs.push_back(r);
                 break;
             }
+            case 4:                                                // AxisAlignedBox(min, max), AxisAlignedBox.cs:15-28
+                if (!(q.p[0] < q.p[3] && q.p[1] < q.p[4] && q.p[2] < q.p[5])) return fail(SR_ERR_INVALID_ARG, "Axis aligned bounding box has bad coordinates (AxisAlignedBox.cs:17-19)");
+                recs.push_back(sr::make_box_record({q.p[0], q.p[1], q.p[2]}, {q.p[3], q.p[4], q.p[5]}));
+                break;
             default: return fail(SR_ERR_INVALID_ARG, "unknown primitive kind");
         }
     }
@@ -1210,8 +1241,42 @@ static int multi_render(sr_scene* m, const sr_frame* f, int32_t* host_pixels, vo
         if (stats4) std::memcpy(stats4, m->last_stats, 4 * sizeof(uint64_t));
         return SR_OK;
     }
-    // device surface on the first part's device: peer-to-peer over xGMI where the first device can read the part's memory,
-    // through pinned host staging where it cannot (sr_create_multi asked; nothing is assumed)
+    // device surface on the first part's device.  SR_GATHER_RCCL: the one exchange step of SURVEY 8e -- grouped ncclSend (every other
+    // part, on the stream its strips were rendered on) / ncclRecv (the first part, on the caller's stream) of the compact strip
+    // buffers over xGMI, then the row de-interleave as strided device copies on the first device
+    if (m->gather_kind == SR_GATHER_RCCL && n > 1) {
+        const sr::RcclApi* api = sr::rccl_api(nullptr);
+        if (!api || (int)m->comms.size() != n) return fail(SR_ERR_NOT_BUILT, "SR_GATHER_RCCL: sr_set_gather has not created the communicators");
+        std::vector<size_t> off(n, 0);
+        size_t total = 0;
+        for (int g = 1; g < n; ++g) { off[g] = total; total += (size_t)counts[g]; }
+        if ((rc = use_device(m->parts[0]))) return rc;
+        SR_HIP(m->d_gather.reserve(std::max<size_t>(total, 1) * 4));
+        SR_RCCL(api, api->GroupStart());
+        for (int g = 1; g < n; ++g) {
+            if (counts[g] == 0) continue;
+            if ((rc = use_device(m->parts[g]))) { (void)api->GroupEnd(); return rc; }
+            SR_RCCL(api, api->Send(m->parts[g]->d_pixels.p, (size_t)counts[g], sr::kRcclInt32, 0, m->comms[g], m->parts[g]->io_stream));
+        }
+        if ((rc = use_device(m->parts[0]))) { (void)api->GroupEnd(); return rc; }
+        for (int g = 1; g < n; ++g) {
+            if (counts[g] == 0) continue;
+            SR_RCCL(api, api->Recv((uint32_t*)m->d_gather.p + off[g], (size_t)counts[g], sr::kRcclInt32, g, m->comms[0], user_stream));
+        }
+        SR_RCCL(api, api->GroupEnd());
+        if (counts[0]) SR_HIP(hipStreamWaitEvent(user_stream, m->parts[0]->multi_done, 0));
+        for (int g = 0; g < n; ++g) {
+            const std::vector<StripRun> runs = strip_runs(a, b, n, g);
+            if (runs.empty() || counts[g] == 0) continue;
+            const uint32_t* src = g == 0 ? (const uint32_t*)m->parts[0]->d_pixels.p : (const uint32_t*)m->d_gather.p + off[g];
+            SR_HIP(copy_runs(runs, n, f->width, src, (uint32_t*)d_pixels, hipMemcpyDeviceToDevice, user_stream));
+        }
+        if (!m->multi_done) SR_HIP(hipEventCreateWithFlags(&m->multi_done, hipEventDisableTiming));
+        SR_HIP(hipEventRecord(m->multi_done, user_stream));
+        return SR_OK;
+    }
+    // SR_GATHER_COPY (default): peer-to-peer over xGMI where the first device can read the part's memory, through pinned host
+    // staging where it cannot (sr_create_multi asked; nothing is assumed)
     for (int g = 0; g < n; ++g) {
         sr_scene* q = m->parts[g];
         const std::vector<StripRun> runs = strip_runs(a, b, n, g);
@@ -1325,38 +1390,173 @@ int sr_render(sr_scene* s, const sr_frame* f, int32_t* pixels, uint64_t stats[4]
     return SR_OK;
 }
 
-int sr_trace_rays(sr_scene* s, int32_t target, int64_t n, const double* starts, const double* dirs, uint8_t* hit, double* ray_frac,
-                  double* pos, double* normal, uint32_t* color, int32_t* tri_index, int32_t* counters) {
+static int trace_prepare(sr_scene*& s, int32_t target, int64_t n, bool have_rays, int& mode, bool& with_extra) {
     if (s && !s->parts.empty()) s = s->parts[0];
-    if (!s || n < 0 || (n > 0 && (!starts || !dirs))) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_trace_rays");
-    bool with_extra = (target & SR_TARGET_ROOT) != 0;
-    int mode = target & 0xff;
+    if (!s || n < 0 || (n > 0 && !have_rays)) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_trace_rays");
+    with_extra = (target & SR_TARGET_ROOT) != 0;
+    mode = target & 0xff;
     if (!s->have_model) return fail(SR_ERR_NO_MODEL, "no model");
     int rc;
     if (s->ntris == 0 && mode == SR_MODE_BRUTE) { /* empty model is fine for brute force */ }
     else if ((rc = check_mode(s, mode))) return rc;
     if ((rc = use_device(s))) return rc;
-    if ((rc = sync_geometry(s, (uint32_t)mode))) return rc;
-    if (n == 0) return SR_OK;
-    size_t sizes[9] = {(size_t)n * 24, (size_t)n * 24, (size_t)n, (size_t)n * 8, (size_t)n * 24, (size_t)n * 24, (size_t)n * 4, (size_t)n * 4, (size_t)n * 12};
-    for (int i = 0; i < 9; ++i) SR_HIP(s->d_io[i].reserve(sizes[i]));
-    SR_HIP(hipMemcpy(s->d_io[0].p, starts, sizes[0], hipMemcpyHostToDevice));
-    SR_HIP(hipMemcpy(s->d_io[1].p, dirs, sizes[1], hipMemcpyHostToDevice));
+    return sync_geometry(s, (uint32_t)mode);
+}
+
+int sr_trace_rays_device(sr_scene* s, int32_t target, int64_t n, const double* d_starts, const double* d_dirs, uint8_t* d_hit, double* d_ray_frac,
+                         double* d_pos, double* d_normal, uint32_t* d_color, int32_t* d_tri_index, int32_t* d_counters, void* hip_stream) {
+    int mode; bool with_extra;
+    int rc = trace_prepare(s, target, n, d_starts && d_dirs, mode, with_extra);
+    if (rc || n == 0) return rc;
     sr::TraceLaunch L{};
     L.sc = dev_scene(s);
     L.mode = mode;
     L.with_extra = with_extra && !s->extra_recs.empty();
     L.n = n;
-    L.starts = (const double*)s->d_io[0].p; L.dirs = (const double*)s->d_io[1].p;
-    L.hit = (uint8_t*)s->d_io[2].p; L.ray_frac = (double*)s->d_io[3].p; L.pos = (double*)s->d_io[4].p; L.normal = (double*)s->d_io[5].p;
-    L.color = (uint32_t*)s->d_io[6].p; L.tri = (int32_t*)s->d_io[7].p; L.counters = (int32_t*)s->d_io[8].p;
-    L.stream = nullptr;
+    L.starts = d_starts; L.dirs = d_dirs;
+    L.hit = d_hit; L.ray_frac = d_ray_frac; L.pos = d_pos; L.normal = d_normal; L.color = d_color; L.tri = d_tri_index; L.counters = d_counters;
+    L.stream = (hipStream_t)hip_stream;
+    hipEvent_t e0, e1;
+    if ((rc = next_events(s, sr::K_TRACE, e0, e1))) return rc;
+    if (e0) SR_HIP(hipEventRecord(e0, L.stream));
     SR_HIP(sr::launch_trace(L));
+    if (e1) SR_HIP(hipEventRecord(e1, L.stream));
+    return SR_OK;
+}
+
+int sr_trace_rays(sr_scene* s, int32_t target, int64_t n, const double* starts, const double* dirs, uint8_t* hit, double* ray_frac,
+                  double* pos, double* normal, uint32_t* color, int32_t* tri_index, int32_t* counters) {
+    int mode; bool with_extra;
+    int rc = trace_prepare(s, target, n, starts && dirs, mode, with_extra);
+    if (rc || n == 0) return rc;
+    size_t sizes[9] = {(size_t)n * 24, (size_t)n * 24, (size_t)n, (size_t)n * 8, (size_t)n * 24, (size_t)n * 24, (size_t)n * 4, (size_t)n * 4, (size_t)n * 12};
+    for (int i = 0; i < 9; ++i) SR_HIP(s->d_io[i].reserve(sizes[i]));
+    SR_HIP(hipMemcpy(s->d_io[0].p, starts, sizes[0], hipMemcpyHostToDevice));
+    SR_HIP(hipMemcpy(s->d_io[1].p, dirs, sizes[1], hipMemcpyHostToDevice));
+    if ((rc = sr_trace_rays_device(s, target, n, (const double*)s->d_io[0].p, (const double*)s->d_io[1].p, (uint8_t*)s->d_io[2].p, (double*)s->d_io[3].p,
+                                   (double*)s->d_io[4].p, (double*)s->d_io[5].p, (uint32_t*)s->d_io[6].p, (int32_t*)s->d_io[7].p, (int32_t*)s->d_io[8].p, nullptr)))
+        return rc;
     SR_HIP(hipStreamSynchronize(nullptr));
     void* outs[7] = {hit, ray_frac, pos, normal, color, tri_index, counters};
     for (int i = 0; i < 7; ++i)
         if (outs[i]) SR_HIP(hipMemcpy(outs[i], s->d_io[2 + i].p, sizes[2 + i], hipMemcpyDeviceToHost));
     return SR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// The RCCL strip gather, native: no PyTorch in the data path.
+// ------------------------------------------------------------------------------------------------------------------
+int sr_set_gather(sr_scene* m, int32_t kind) {
+    if (!m || (kind != SR_GATHER_COPY && kind != SR_GATHER_RCCL)) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_set_gather");
+    if (m->parts.empty()) return fail(SR_ERR_INVALID_ARG, "sr_set_gather: not a multi-device scene (sr_create_multi)");
+    if (kind == SR_GATHER_RCCL && m->comms.empty() && m->parts.size() > 1) {
+        std::string why;
+        const sr::RcclApi* api = sr::rccl_api(&why);
+        if (!api) return fail(SR_ERR_UNSUPPORTED, why);
+        std::vector<int> devs;
+        for (sr_scene* q : m->parts) devs.push_back(q->device);
+        for (size_t i = 0; i < devs.size(); ++i)
+            for (size_t j = i + 1; j < devs.size(); ++j)
+                if (devs[i] == devs[j]) return fail(SR_ERR_UNSUPPORTED, "SR_GATHER_RCCL needs distinct devices (RCCL refuses two ranks on one GPU)");
+        std::vector<sr::RcclComm> comms(devs.size(), nullptr);
+        SR_RCCL(api, api->CommInitAll(comms.data(), (int)devs.size(), devs.data()));
+        for (sr_scene* q : m->parts) { int rc = use_device(q); if (rc) return rc; rc = ensure_io_streams(q); if (rc) return rc; }
+        m->comms.swap(comms);
+    }
+    m->gather_kind = kind;
+    return SR_OK;
+}
+
+int sr_rccl_unique_id(uint8_t out[SR_RCCL_ID_BYTES]) {
+    if (!out) return fail(SR_ERR_INVALID_ARG, "out is NULL");
+    std::string why;
+    const sr::RcclApi* api = sr::rccl_api(&why);
+    if (!api) return fail(SR_ERR_UNSUPPORTED, why);
+    static_assert(SR_RCCL_ID_BYTES == sr::kRcclIdBytes, "ncclUniqueId is 128 bytes");
+    sr::RcclId id;
+    SR_RCCL(api, api->GetUniqueId(&id));
+    std::memcpy(out, id.internal, SR_RCCL_ID_BYTES);
+    return SR_OK;
+}
+
+int sr_rccl_init(sr_scene* s, const uint8_t id_bytes[SR_RCCL_ID_BYTES], int32_t world, int32_t rank) {
+    if (!s || !id_bytes || world < 1 || rank < 0 || rank >= world) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_rccl_init");
+    if (!s->parts.empty()) return fail(SR_ERR_INVALID_ARG, "sr_rccl_init: one scene = one rank = one device (use sr_set_gather for a multi-device scene)");
+    std::string why;
+    const sr::RcclApi* api = sr::rccl_api(&why);
+    if (!api) return fail(SR_ERR_UNSUPPORTED, why);
+    int rc = use_device(s);
+    if (rc) return rc;
+    if (s->comm) { SR_RCCL(api, api->CommDestroy(s->comm)); s->comm = nullptr; }
+    sr::RcclId id;
+    std::memcpy(id.internal, id_bytes, SR_RCCL_ID_BYTES);
+    SR_RCCL(api, api->CommInitRank(&s->comm, world, id, rank));
+    s->rccl_world = world; s->rccl_rank = rank;
+    return SR_OK;
+}
+
+int sr_rccl_gather(sr_scene* s, const sr_frame* f, const void* d_strips, void* d_full, void* hip_stream) {
+    if (!s || !s->parts.empty()) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_rccl_gather");
+    if (!s->comm) return fail(SR_ERR_NOT_BUILT, "sr_rccl_gather before sr_rccl_init");
+    int rc = validate_frame(f);
+    if (rc) return rc;
+    const sr::RcclApi* api = sr::rccl_api(nullptr);
+    if (!api) return fail(SR_ERR_UNSUPPORTED, "librccl is not loaded");
+    if ((rc = use_device(s))) return rc;
+    const int n = s->rccl_world, me = s->rccl_rank;
+    if (me == 0 && !d_full) return fail(SR_ERR_INVALID_ARG, "rank 0 needs the full surface");
+    int a, b;
+    clamp_rows(f, a, b);
+    if (b < a) return SR_OK;
+    std::vector<size_t> counts(n, 0), off(n, 0);
+    size_t total = 0;
+    for (int g = 0; g < n; ++g) {
+        sr_frame fg = *f;
+        fg.strip_rows = kMultiStripRows; fg.strip_count = n; fg.strip_index = g;
+        counts[g] = (size_t)sr_frame_pixel_count(&fg);
+        if (g > 0) { off[g] = total; total += counts[g]; }
+    }
+    if (counts[me] && !d_strips) return fail(SR_ERR_INVALID_ARG, "this rank owns rows but passed no strip buffer");
+    hipStream_t stream = (hipStream_t)hip_stream;
+    if (me != 0) {
+        if (counts[me] == 0) return SR_OK;
+        SR_RCCL(api, api->GroupStart());
+        SR_RCCL(api, api->Send(d_strips, counts[me], sr::kRcclInt32, 0, s->comm, stream));
+        SR_RCCL(api, api->GroupEnd());
+        return SR_OK;
+    }
+    SR_HIP(s->d_gather.reserve(std::max<size_t>(total, 1) * 4));
+    if (n > 1) {
+        SR_RCCL(api, api->GroupStart());
+        for (int g = 1; g < n; ++g)
+            if (counts[g]) SR_RCCL(api, api->Recv((uint32_t*)s->d_gather.p + off[g], counts[g], sr::kRcclInt32, g, s->comm, stream));
+        SR_RCCL(api, api->GroupEnd());
+    }
+    for (int g = 0; g < n; ++g) {                                     // the row de-interleave: strided device copies behind the receives
+        const std::vector<StripRun> runs = strip_runs(a, b, n, g);
+        if (runs.empty() || counts[g] == 0) continue;
+        const uint32_t* src = g == 0 ? (const uint32_t*)d_strips : (const uint32_t*)s->d_gather.p + off[g];
+        SR_HIP(copy_runs(runs, n, f->width, src, (uint32_t*)d_full, hipMemcpyDeviceToDevice, stream));
+    }
+    return SR_OK;
+}
+
+int sr_rccl_render(sr_scene* s, const sr_frame* f, void* d_full, void* hip_stream) {
+    if (!s || !s->parts.empty()) return fail(SR_ERR_INVALID_ARG, "bad argument to sr_rccl_render");
+    if (!s->comm) return fail(SR_ERR_NOT_BUILT, "sr_rccl_render before sr_rccl_init");
+    int rc = validate_frame(f);
+    if (rc) return rc;
+    if (f->strip_count > 0) return fail(SR_ERR_INVALID_ARG, "sr_rccl_render splits the frame itself: strip_count must be 0");
+    if ((f->flags & SR_F_STATIC_SHADOWS) && (f->flags & SR_F_SHADOWS)) return fail(SR_ERR_UNSUPPORTED, "static shadows need the whole frame on one device");
+    if ((rc = use_device(s))) return rc;
+    sr_frame fg = *f;
+    fg.strip_rows = kMultiStripRows; fg.strip_count = s->rccl_world; fg.strip_index = s->rccl_rank;
+    const int64_t mine = sr_frame_pixel_count(&fg);
+    if (mine > 0) {
+        SR_HIP(s->d_pixels.reserve((size_t)mine * 4));
+        if ((rc = sr_render_device(s, &fg, s->d_pixels.p, hip_stream, nullptr))) return rc;
+    }
+    return sr_rccl_gather(s, f, mine > 0 ? s->d_pixels.p : nullptr, d_full, hip_stream);
 }
 
 int sr_shade_points(sr_scene* s, const sr_frame* f, int64_t n, const double* pos, const double* normal, const uint32_t* color, uint32_t* out) {
@@ -1419,6 +1619,12 @@ void sr_make_random_triangles(int32_t seed, int64_t n, double space, double exte
         uint32_t c = (uint32_t)rnd.next();                                              // (uint)random.Next()
         argb[i] = opaque ? (0xFF000000u | (c & 0xFFFFFFu)) : c;
     }
+}
+
+void sr_net_random_doubles(int32_t seed, int64_t skip, int64_t n, double* out) {
+    sr::NetRandom rnd(seed);
+    for (int64_t i = 0; i < skip; ++i) (void)rnd.next();           // Next() and NextDouble() both consume one sample
+    for (int64_t i = 0; i < n; ++i) out[i] = rnd.next_double();
 }
 
 // ---- surface passes, Renderer.cs:765-767 ----

@@ -111,6 +111,16 @@ Rec128 make_plane_record(Vec3 point, Vec3 normal, uint32_t color) {
     r.aux = 1;
     return r;
 }
+Rec128 make_box_record(Vec3 mn, Vec3 mx) {
+    Rec128 r;
+    std::memset(&r, 0, sizeof(r));
+    r.p[0] = mn.x; r.p[1] = mn.y; r.p[2] = mn.z; r.p[3] = mx.x; r.p[4] = mx.y; r.p[5] = mx.z;
+    const Vec3 nrm[6] = {{-1, 0, 0}, {0, -1, 0}, {0, 0, -1}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 6; ++i) r.p[6 + i] = make_plane_record(i < 3 ? mn : mx, nrm[i], 0).p[3];   // new Plane(min / max, normal).originDist
+    r.color = 0xffffffffu;                                 // a hit carries its plane's colour: Color.White (Plane.cs:28)
+    r.aux = 4;
+    return r;
+}
 RootBox make_root_box(const double bmin[3], const double bmax[3]) {
     RootBox b;
     const double eps = 1e-10;

@@ -32,6 +32,7 @@ private:
 Rec128 make_triangle_record(Vec3 v1, Vec3 v2, Vec3 v3, uint32_t color, int32_t aux);  // Triangle.cs:29-57
 Rec128 make_sphere_record(Vec3 centre, double radius, uint32_t color);                // Sphere.cs:26-33
 Rec128 make_plane_record(Vec3 point, Vec3 normal, uint32_t color);                    // Plane.cs:22-29
+Rec128 make_box_record(Vec3 mn, Vec3 mx);                                             // AxisAlignedBox.cs:15-28 (six Plane objects, Color.White)
 RootBox make_root_box(const double bmin[3], const double bmax[3]);                    // AxisAlignedBox.cs:16-28
 
 // ---- reference tree (SpatialSubdivision.cs:49-315) flattened ----

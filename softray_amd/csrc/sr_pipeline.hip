@@ -379,12 +379,9 @@ __device__ __forceinline__ bool extras_block(const DevScene& sc, D3 rs, D3 rd, C
     for (int i = 0; i < sc.nextra; ++i) {
         const Rec128* r = &sc.extra[i];
         double t; D3 pos, nrm;
-        bool ok;
-        int kind = r->aux;
-        if (kind == 0) ok = sphere_hit(r->p, rs, rd, t, pos, nrm);
-        else if (kind == 1) ok = plane_hit(r->p, rs, rd, t, pos);
-        else ok = tri_hit(r->p, rs, rd, t, pos);
-        c.geom++;
+        uint32_t tests;
+        const bool ok = extra_hit(r, rs, rd, t, pos, nrm, tests);
+        c.geom += tests;
         if (ok && t <= 1.0) return true;
     }
     return false;
@@ -2170,12 +2167,9 @@ __global__ __launch_bounds__(256) void k_bounce(DevScene sc, FrameConst fc, cons
                         for (int i = 0; i < sc.nextra; ++i) {
                             const Rec128* e = &sc.extra[i];
                             double t; D3 pos, nrm;
-                            bool ok;
-                            const int kind = e->aux;
-                            if (kind == 0) ok = sphere_hit(e->p, s0, d, t, pos, nrm);
-                            else if (kind == 1) { ok = plane_hit(e->p, s0, d, t, pos); nrm = mk(e->p[0], e->p[1], e->p[2]); }
-                            else { ok = tri_hit(e->p, s0, d, t, pos); nrm = mk(e->p[0], e->p[1], e->p[2]); }
-                            sec.geom++;
+                            uint32_t tests;
+                            const bool ok = extra_hit(e, s0, d, t, pos, nrm, tests);
+                            sec.geom += tests;
                             if (ok && t < ex_t) { ex_t = t; ex_pos = pos; ex_nrm = nrm; ex_color = e->color; }
                         }
                     }
@@ -2527,12 +2521,9 @@ __global__ __launch_bounds__(256) void k_bounce_finish(DevScene sc, FrameConst f
             for (int i = 0; i < sc.nextra; ++i) {
                 const Rec128* e = &sc.extra[i];
                 double t; D3 pos, nrm;
-                bool ok;
-                const int kind = e->aux;
-                if (kind == 0) ok = sphere_hit(e->p, s0, d, t, pos, nrm);
-                else if (kind == 1) { ok = plane_hit(e->p, s0, d, t, pos); nrm = mk(e->p[0], e->p[1], e->p[2]); }
-                else { ok = tri_hit(e->p, s0, d, t, pos); nrm = mk(e->p[0], e->p[1], e->p[2]); }
-                n_geom++;
+                uint32_t tests;
+                const bool ok = extra_hit(e, s0, d, t, pos, nrm, tests);
+                n_geom += tests;
                 if (ok && t < ex_t) { ex_t = t; ex_pos = pos; ex_nrm = nrm; ex_color = e->color; }
             }
         }
@@ -3117,6 +3108,7 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
             if ((e = hipMemcpyAsync(L.counters, L.counters + 13, 4, hipMemcpyDeviceToDevice, L.stream)) != hipSuccess) return e;
             PipelineLaunch G = L;
             G.hits = L.static_hits;
+            if (L.primary_stats_only) G.stats = nullptr;
             e = launch_shadow_t<MODE, EXTRA>(G, samples, std::min<long long>(max_hits, (long long)kStaticRes * kStaticRes * kStaticRes));
             if (e != hipSuccess) return e;
             hipLaunchKernelGGL(k_static_apply, dim3(blocks), dim3(256), 0, L.stream, (const uint8_t*)L.sc.shadow_cache, (const HitRec*)L.hits, L.counters + 14, samples);
@@ -3124,6 +3116,7 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
         } else if (shadows) {
             // (queue entries are counted in whole tiles: see pad_tiles)
             PipelineLaunch T = L;                                    // this band's queue is tile-indexed (k_primary above)
+            if (L.primary_stats_only) T.stats = nullptr;             // (the four statistics of sr_render count primary rays: no atomics per hit point)
             T.tile_queue_n2 = pad_tiles ? n2 : 0;
             T.tile_queue_rows = row_count;
             const long long max_hits = (long long)((row_count + 15) / 16 * 16) * ((L.fc.width + 15) / 16 * 16) * n2;

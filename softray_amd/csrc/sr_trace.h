@@ -96,6 +96,37 @@ __device__ __forceinline__ bool sphere_hit(const double* p, D3 s, D3 d, double& 
     return true;
 }
 
+// AxisAlignedBox.IntersectRay (AxisAlignedBox.cs:60-95) on p = {min, max, originDist of the six planes in the constructor's
+// order -x, -y, -z, +x, +y, +z (:22-27)}: the nearest of the six one-sided plane hits that lies on the box (ContainsPoint, 1e-10 slack)
+__device__ __forceinline__ bool box_hit(const double* p, D3 s, D3 d, double& t, D3& pos, D3& nrm) {
+    double best = DBL_MAX;
+    bool any = false;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const double sg = i < 3 ? -1.0 : 1.0;
+        const double pl[4] = {(i % 3) == 0 ? sg : 0.0, (i % 3) == 1 ? sg : 0.0, (i % 3) == 2 ? sg : 0.0, p[6 + i]};
+        double rf; D3 q;
+        if (plane_hit(pl, s, d, rf, q) && rf < best) {
+            if (p[0] - 1e-10 < q.x && q.x < p[3] + 1e-10 && p[1] - 1e-10 < q.y && q.y < p[4] + 1e-10 && p[2] - 1e-10 < q.z && q.z < p[5] + 1e-10) {
+                best = rf; pos = q; nrm = mk(pl[0], pl[1], pl[2]); any = true;
+            }
+        }
+    }
+    t = best;
+    return any;
+}
+
+// one element of ExtraGeometryToRaytrace (Rec128.aux: 0 Sphere, 1 Plane, 2 Triangle, 4 AxisAlignedBox); returns its NumRayTests in `tests`
+__device__ __forceinline__ bool extra_hit(const Rec128* r, D3 s, D3 d, double& t, D3& pos, D3& nrm, uint32_t& tests) {
+    const int kind = r->aux;
+    tests = 1;
+    if (kind == 0) return sphere_hit(r->p, s, d, t, pos, nrm);
+    if (kind == 4) { tests = 6; return box_hit(r->p, s, d, t, pos, nrm); }          // six planes (AxisAlignedBox.cs:70)
+    nrm = mk(r->p[0], r->p[1], r->p[2]);
+    if (kind == 1) return plane_hit(r->p, s, d, t, pos);
+    return tri_hit(r->p, s, d, t, pos);
+}
+
 // --------------------------------------------------------------------------------------------------
 // root-box clip (AxisAlignedBox.ContainsPoint / IntersectLineSegment / ClipLineSegment)
 // --------------------------------------------------------------------------------------------------
@@ -671,12 +702,9 @@ __device__ bool root_intersect_pkt(const DevScene& sc, const Rec128* extra, int3
         for (int i = 0; i < sc.nextra; ++i) {
             const Rec128* r = &extra[i];
             double t; D3 pos, nrm;
-            bool ok;
-            int kind = r->aux;
-            if (kind == 0) ok = sphere_hit(r->p, s, d, t, pos, nrm);
-            else if (kind == 1) { ok = plane_hit(r->p, s, d, t, pos); nrm = mk(r->p[0], r->p[1], r->p[2]); }
-            else { ok = tri_hit(r->p, s, d, t, pos); nrm = mk(r->p[0], r->p[1], r->p[2]); }
-            c.geom++;
+            uint32_t tests;
+            const bool ok = extra_hit(r, s, d, t, pos, nrm, tests);
+            c.geom += tests;
             if (ok && t < best) {
                 best = t; any = true;
                 out.t = t; out.pos = pos; out.nrm = nrm; out.color = r->color; out.tri = -1;
@@ -732,12 +760,9 @@ __device__ bool root_intersect(const DevScene& sc, const Rec128* tris, const Rec
     for (int i = 0; i < sc.nextra; ++i) {
         const Rec128* r = &extra[i];
         double t; D3 pos, nrm;
-        bool ok;
-        int kind = r->aux;
-        if (kind == 0) ok = sphere_hit(r->p, s, d, t, pos, nrm);
-        else if (kind == 1) { ok = plane_hit(r->p, s, d, t, pos); nrm = mk(r->p[0], r->p[1], r->p[2]); }
-        else { ok = tri_hit(r->p, s, d, t, pos); nrm = mk(r->p[0], r->p[1], r->p[2]); }
-        c.geom++;
+        uint32_t tests;
+        const bool ok = extra_hit(r, s, d, t, pos, nrm, tests);
+        c.geom += tests;
         if (ok && t < best) {
             best = t; any = true;
             out.t = t; out.pos = pos; out.nrm = nrm; out.color = r->color; out.tri = -1;

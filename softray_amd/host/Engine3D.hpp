@@ -86,9 +86,16 @@ struct Triangle {                                          // Triangle.cs:29-57
     Triangle(Vector a, Vector b, Vector c, uint32_t col) : v1(a), v2(b), v3(c), color(col) {}
 };
 
+struct AxisAlignedBox {                                    // AxisAlignedBox.cs:15-28 as an IRayIntersectable (IntersectRay :60-95)
+    Vector Min, Max;
+    AxisAlignedBox(Vector mn, Vector mx) : Min(mn), Max(mx) {
+        if (!(mn.x < mx.x && mn.y < mx.y && mn.z < mx.z)) throw std::invalid_argument("Axis aligned bounding box has bad coordinates");
+    }
+};
+
 class GeometryCollection {                                 // GeometryCollection.cs:8-31
 public:
-    using Item = std::variant<Sphere, Plane, Triangle>;
+    using Item = std::variant<Sphere, Plane, Triangle, AxisAlignedBox>;
     void Add(const Item& g) { items_.push_back(g); }
     int Count() const { return (int)items_.size(); }
     std::vector<sr_prim> ToPrims() const {
@@ -102,6 +109,9 @@ public:
                 p.kind = 1; p.argb = pl->Color.ToARGB();
                 p.p[0] = pl->point.x; p.p[1] = pl->point.y; p.p[2] = pl->point.z;
                 p.p[3] = pl->normal.x; p.p[4] = pl->normal.y; p.p[5] = pl->normal.z;
+            } else if (auto b = std::get_if<AxisAlignedBox>(&it)) {
+                p.kind = 4; p.argb = 0xffffffffu;          // its six planes are Color.White (Plane.cs:28)
+                p.p[0] = b->Min.x; p.p[1] = b->Min.y; p.p[2] = b->Min.z; p.p[3] = b->Max.x; p.p[4] = b->Max.y; p.p[5] = b->Max.z;
             } else {
                 const Triangle& t = std::get<Triangle>(it);
                 p.kind = 2; p.argb = t.color;
@@ -182,7 +192,7 @@ public:
     // NumRaysFired is exact in every mode; shadow rays take the shaft path on the own BVH in all three (same pixels).
     enum class TraversalCounters { Auto, Literal, Off };
     const TraversalCounters gpuTraversalCounters;
-    int gpuOwnBvhThreshold = 20000;
+    int gpuOwnBvhThreshold = 2000;
     int gpuMaxBounces = 0;          // config-5 extension: mirror bounces (0 = the reference's behaviour)
     double gpuReflectivity = 0.0;
     std::vector<std::shared_ptr<Instance>> Instances;
@@ -294,7 +304,8 @@ public:
         f.flags = (rayTraceShading ? SR_F_SHADING : 0u) | (rayTraceShadows ? SR_F_SHADOWS : 0u) |
                   (rayTraceShadows && rayTraceShadowsStatic ? SR_F_STATIC_SHADOWS : 0u) |      // Renderer.cs:1625; the cache lives in the scene
                   (rayTraceFocalBlur ? SR_F_FOCAL_BLUR : 0u) |
-                  (pointLighting ? SR_F_POINT_LIGHT : 0u) | (specularLighting ? SR_F_SPECULAR : 0u);
+                  (pointLighting ? SR_F_POINT_LIGHT : 0u) | (specularLighting ? SR_F_SPECULAR : 0u) |
+                  SR_F_PRIMARY_STATS_ONLY;                 // Num* count primary rays (Renderer.cs:1916-1923)
         f.random_seed = rayTraceRandomSeed;
         f.trace_mode = Mode();
         f.max_bounces = gpuMaxBounces;

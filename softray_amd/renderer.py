@@ -102,6 +102,18 @@ class Triangle:
         return (2, self.color, list(self.v1) + list(self.v2) + list(self.v3))
 
 
+class AxisAlignedBox:
+    """Raytrace.AxisAlignedBox as an IRayIntersectable (AxisAlignedBox.cs:15-28, IntersectRay :60-95): six one-sided white planes."""
+
+    def __init__(self, min, max):
+        if not (min.x < max.x and min.y < max.y and min.z < max.z):
+            raise ValueError("Axis aligned bounding box has bad coordinates")       # Contract.Requires, :17-19
+        self.Min, self.Max = min, max
+
+    def _prim(self):
+        return (4, 0xffffffff, list(self.Min) + list(self.Max))
+
+
 class GeometryCollection:
     """Raytrace.GeometryCollection (GeometryCollection.cs:8-31): ordered list of primitives."""
 
@@ -246,7 +258,7 @@ class Renderer:
         # pixels either way except for the documented 1e-10 leaf-face case (include/softray.h SR_MODE_BVH), which is one more
         # reason why models of the reference's own sizes keep the literal tree by default.  obj.3DS at 1024^2: 0.36 ms literal,
         # 0.17 ms on the own BVH
-        self.gpuOwnBvhThreshold = 20000
+        self.gpuOwnBvhThreshold = 2000
         self.gpuTreeMaxDepth = 0              # 0 => SpatialSubdivision defaults 15 / 25
         self.gpuTreeMaxGeometryPerNode = 0
         self.gpuMaxBounces = 0                # config-5 extension: mirror bounces (0 = reference behaviour)
@@ -478,7 +490,7 @@ class Renderer:
             flags |= F_POINT_LIGHT
         if self.specularLighting:
             flags |= F_SPECULAR
-        f.flags = flags
+        f.flags = flags | _lib.F_PRIMARY_STATS_ONLY               # Num* count primary rays (Renderer.cs:1916-1923)
         f.random_seed = self.rayTraceRandomSeed
         f.shadow_samples = 0
         f.trace_mode = self._mode()
@@ -523,5 +535,5 @@ class Renderer:
             self._haveCounters = False
 
 
-__all__ = ["Renderer", "Style", "TraversalCounters", "InvalidOperationException", "Instance", "Model", "GeometryCollection", "Sphere", "Plane", "Triangle", "Vector", "Color",
+__all__ = ["Renderer", "Style", "TraversalCounters", "InvalidOperationException", "Instance", "Model", "GeometryCollection", "Sphere", "Plane", "Triangle", "AxisAlignedBox", "Vector", "Color",
            "MODE_REF_TREE", "MODE_BRUTE", "MODE_BVH"]

@@ -205,6 +205,44 @@ class GpuScene:
         return res
 
 
+    def trace_device(self, target, n, d_starts, d_dirs, d_hit=0, d_ray_frac=0, d_pos=0, d_normal=0, d_color=0, d_tri_index=0, d_counters=0, stream=0):
+        """sr_trace_rays_device: every array is a DEVICE pointer (e.g. tensor.data_ptr()); enqueued on `stream`, no host sync."""
+        vp = lambda x: C.c_void_p(x) if x else None
+        _check(_lib.lib().sr_trace_rays_device(self._h, int(target), int(n), vp(d_starts), vp(d_dirs), vp(d_hit), vp(d_ray_frac), vp(d_pos),
+                                               vp(d_normal), vp(d_color), vp(d_tri_index), vp(d_counters), vp(stream)))
+
+    # ---- the strip gather over RCCL (include/softray.h) ----
+    def set_gather(self, kind):
+        """Multi-device scene: _lib.GATHER_COPY (peer copies, default) or _lib.GATHER_RCCL (grouped ncclSend / ncclRecv)."""
+        _check(_lib.lib().sr_set_gather(self._h, int(kind)))
+
+    def rccl_init(self, unique_id, world, rank):
+        buf = (C.c_uint8 * _lib.RCCL_ID_BYTES).from_buffer_copy(bytes(unique_id))
+        _check(_lib.lib().sr_rccl_init(self._h, buf, int(world), int(rank)))
+
+    def rccl_render(self, frame, d_full_ptr, stream=0):
+        """Render this rank's strips of `frame` and gather every rank's on rank 0 (d_full_ptr: device int32[W*H] there, 0 elsewhere)."""
+        _check(_lib.lib().sr_rccl_render(self._h, C.byref(frame), C.c_void_p(d_full_ptr) if d_full_ptr else None, C.c_void_p(stream) if stream else None))
+
+    def rccl_gather(self, frame, d_strips_ptr, d_full_ptr, stream=0):
+        _check(_lib.lib().sr_rccl_gather(self._h, C.byref(frame), C.c_void_p(d_strips_ptr) if d_strips_ptr else None,
+                                         C.c_void_p(d_full_ptr) if d_full_ptr else None, C.c_void_p(stream) if stream else None))
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId through the library (rank 0); hand the 128 bytes to the other ranks."""
+    buf = (C.c_uint8 * _lib.RCCL_ID_BYTES)()
+    _check(_lib.lib().sr_rccl_unique_id(buf))
+    return bytes(buf)
+
+
+def net_random_doubles(seed, n, skip=0):
+    """n NextDouble() of System.Random(seed) after `skip` samples."""
+    out = np.zeros(int(n))
+    _lib.lib().sr_net_random_doubles(int(seed), int(skip), int(n), _p(out))
+    return out
+
+
 def make_random_triangles(n, seed=12345, space=100.0, extent=10.0, origin=0.0, opaque=False):
     """SpatialSubdivisionTests.MakeRandomTriangles with the library's System.Random port."""
     v9 = np.zeros((int(n), 3, 3))

@@ -27,7 +27,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(L, n), "libsoftray_hip.so does not export %s" % n
     assert sorted(sa._lib.SYMBOLS) == names
-    assert L.sr_abi_version() == 4              # 24 ray statistics (SR_STATS_COUNT)
+    assert L.sr_abi_version() == 5              # 24 ray statistics (SR_STATS_COUNT); 5: sr_trace_rays_device, the sr_rccl_* gather
 
 
 def test_frame_layout_matches_oracle_frame():

@@ -174,6 +174,27 @@ def test_sphere_hit_rates():
     assert r["hit"][0] == 1 and abs(r["ray_frac"][0] - 8.5) < 1e-12
 
 
+def test_aabb_as_ray_intersectable():
+    """AxisAlignedBox.IntersectRay (AxisAlignedBox.cs:60-95): six one-sided planes + ContainsPoint.  RayIntersectAABBPerformance's rays
+    (TriangleTests.cs:322-344: starts above the unit box, directions downwards) hit 99.8-100 %; a ray from inside hits nothing (every
+    plane faces outwards); the hit carries the plane's unit normal and Color.White."""
+    s = orc.Scene()
+    s.set_triangles(np.zeros((0, 3, 3)), np.zeros(0, dtype=np.uint32), [-1, -1, -1], [1, 1, 1])
+    s.set_extra([(4, 0xff123456, [-0.5, -0.5, -0.5, 0.5, 0.5, 0.5])])
+    rnd = orc.Random(12345)
+    u = rnd.NextDoubles(6 * 200000).reshape(-1, 6)
+    starts = np.stack([-0.3 + 0.6 * u[:, 0], -0.3 + 0.6 * u[:, 1], 0.5 + 0.5 * u[:, 2]], axis=1)
+    dirs = np.stack([-0.5 + u[:, 3], -0.5 + u[:, 4], np.full(u.shape[0], -1.0)], axis=1)
+    r = s.trace(2, starts, dirs, counters=True)
+    assert 0.998 < r["hit"].mean() <= 1.0
+    h = r["hit"].astype(bool)
+    assert np.all(r["normal"][h] == np.array([0.0, 0.0, 1.0])) and np.all(r["pos"][h][:, 2] == 0.5) and np.all(r["color"][h] == 0xffffffff)
+    assert np.all(r["counters"][:, 0] == 6)                               # NumRayTests: six planes (:70)
+    r = s.trace(2, [[0.0, 0.0, 0.0], [2.0, 0.1, 0.2], [2.0, 0.1, 0.2]], [[1.0, 0.2, 0.3], [-1.0, 0.0, 0.0], [1.0, 0.0, 0.0]])
+    assert list(r["hit"]) == [0, 1, 0]
+    assert r["ray_frac"][1] == 1.5 and np.all(r["normal"][1] == [1.0, 0.0, 0.0])
+
+
 def test_3ds_loader_facts():
     v9, argb, bmin, bmax = load_obj3ds()
     assert v9.shape == (152, 3, 3)                       # SURVEY 8: obj.3DS = 152 tris
