@@ -679,7 +679,7 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
                 accum_fresh = true;                                // zeroed on the half's own stream below
             }
         }
-        SR_HIP(B.counters.reserve(64));
+        SR_HIP(B.counters.reserve(sr::pipeline_counter_bytes()));
         hipStream_t bs = stream;
         if (split) {
             if (!B.stream) SR_HIP(hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));

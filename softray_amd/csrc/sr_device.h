@@ -133,6 +133,7 @@ int pipeline_round_cap(int round);
 int pipeline_round_cap_max(int round);
 int pipeline_bounce_lds_levels();      // stack levels per lane k_bounce_walk keeps in LDS (deeper ones live in PipelineLaunch::bounce_stack)
 size_t pipeline_round_state_bytes();
+size_t pipeline_counter_bytes();
 
 // Own BVH built on the device (sr_lbvh.hip).  Inputs in TriangleIndex order, outputs caller-allocated (n entries each).
 hipError_t gather_records_device(int n, const unsigned int* d_order, const Rec128* d_tris, Rec128* d_btris, const TriSlab* d_slab_in,

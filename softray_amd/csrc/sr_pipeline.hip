@@ -88,6 +88,68 @@ static int xcd_tile_grid(int width, int row_count) {
     return spx * 8 * sny * 64;
 }
 
+// A kernel argument read WHERE IT IS NEEDED, from the kernel-argument segment (byte offset `offset`), through a pointer the
+// compiler cannot see through: it loads every argument it can name at the top of the kernel and keeps it in scalar registers
+// for good -- the root box alone is 48 of them, which a rare FP64 path needs and the loop around it then pays for with
+// v_readlane / v_writelane spills.
+template <typename T>
+__device__ __forceinline__ T kernarg_late(size_t offset) {
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "whole 32-bit words");
+    typedef const uint32_t __attribute__((address_space(4))) CW4;
+    CW4* kp = (CW4*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    T out;
+    uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) o[i] = kp[offset / 4 + i];
+    return out;
+}
+
+// the first two arguments of the pipeline kernels as the kernel-argument segment holds them
+struct SceneFrameArgs { DevScene sc; FrameConst fc; };
+
+// Work distribution of the tile kernels (k_primary, k_shaft_pkt4).  Virtual block vb of the XCD-aware tile grid is one 16x16-pixel
+// tile, its four waves vq = 0..3 are the tile's 8x8-pixel quadrants.  Direct mode (heads == nullptr): workgroup = virtual block,
+// one item per wave.  Persistent mode: a fixed grid of resident workgroups whose WAVES pull (vb, vq) items from eight counters, one
+// per XCD, each enumerating that XCD's virtual blocks (vb % 8 == xcd: the blocks the dispatcher would have dealt to it) in
+// ascending order -- the order, and the XCD, of direct mode, so the XCD-local L2 sees the same tiles -- and, when its own XCD's
+// list is used up, from the other XCDs' (load balance at the end of the launch).  Counters live 64 bytes apart, are zeroed by the
+// host before the launch and may overshoot.  Workgroups are dealt to XCDs round-robin (blockIdx.x % 8).
+constexpr int kTileHeadStride = 16;      // uints between two XCDs' counters
+template <bool PERSIST>
+struct TileFeed {
+    unsigned int* heads;
+    unsigned int per_xcd, home, visit;
+    int wave, lane;
+    bool direct_done;
+    __device__ __forceinline__ TileFeed(unsigned int* h, unsigned int virtual_blocks, int w, int l)
+        : heads(h), per_xcd((virtual_blocks >> 3) * 4u), home(blockIdx.x & 7u), visit(0u), wave(w), lane(l), direct_done(false) {}
+    __device__ __forceinline__ bool next(unsigned int& vb, unsigned int& vq) {
+        if (!PERSIST) {
+            if (direct_done) return false;
+            direct_done = true;
+            vb = blockIdx.x; vq = (unsigned)wave;
+            return true;
+        }
+        while (visit < 8u) {
+            const unsigned int x = (home + visit) & 7u;
+            unsigned int t = 0;
+            if (lane == 0) t = atomicAdd(&heads[x * kTileHeadStride], 1u);
+            t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
+            if (t < per_xcd) { vb = (t >> 2) * 8u + x; vq = t & 3u; return true; }
+            ++visit;
+        }
+        return false;
+    }
+};
+// scene / frame of a tile kernel's iteration: the plain kernel arguments in direct mode (one iteration: nothing to hoist), read late
+// from the kernel-argument segment in persistent mode (see k_shaft_pkt4)
+template <bool PERSIST, class T>
+__device__ __forceinline__ T tile_arg(const T& plain, size_t offset) {
+    if constexpr (PERSIST) return kernarg_late<T>(offset);
+    else return plain;
+}
+
 // --------------------------------------------------------------------------------------------------
 // k_primary
 // --------------------------------------------------------------------------------------------------
@@ -97,19 +159,31 @@ static int xcd_tile_grid(int width, int row_count) {
 // PKT = 2: the packet walk on the four-wide tree's camera-ordered copy (bvh4_packet_nearest), the default; PKT = 3: the same with the
 // camera outside the root box's slab on all three axes (the copy holds (near, far) planes: no min / max per axis); PKT = 1: on the
 // binary tree with a per-step vote (cross-check)
-template <int MODE, bool EXTRA, bool STATS, bool SUB, int PKT>
-__global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, FrameConst fc, const int32_t* __restrict__ row_map, int row_begin,
+template <int MODE, bool EXTRA, bool STATS, bool SUB, int PKT, bool PERSIST>
+__global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc_arg, FrameConst fc_arg, const int32_t* __restrict__ row_map, int row_begin,
                                                  int row_count, uint32_t* __restrict__ samples, HitRec* __restrict__ hits,
                                                  unsigned int* __restrict__ hit_count, uint32_t* __restrict__ bounce_levels,
-                                                 uint8_t* __restrict__ bounce_nlev, unsigned long long* stats, int pad_tiles, int levels) {
+                                                 uint8_t* __restrict__ bounce_nlev, unsigned long long* stats, int pad_tiles, int levels,
+                                                 unsigned int* __restrict__ tile_heads, unsigned int virtual_blocks) {
     const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    int32_t* wnode = reinterpret_cast<int32_t*>(lds_pipe) + (size_t)__builtin_amdgcn_readfirstlane(wave) * levels;   // PKT: the wave's node stack
+    const int pwave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int32_t* wnode = reinterpret_cast<int32_t*>(lds_pipe) + (size_t)pwave * levels;   // PKT: the wave's node stack
+    Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
+    Ctr prim = {0, 0, 0, 0};
+    // (work items: see TileFeed -- direct mode = one workgroup per 16x16 tile, persistent mode = waves pulling 8x8 quadrants)
+    TileFeed<PERSIST> feed(tile_heads, virtual_blocks, pwave, lane);
+    unsigned int vb, vq;
+    while (feed.next(vb, vq)) {
+    // Scene and frame are read from the kernel-argument segment WHERE an iteration needs them (kernarg_late): the ray set-up's inputs
+    // here, the walk's before the walk, the shading's after it.  Read as plain kernel arguments, the compiler hoists them -- and what it
+    // derives from them -- out of this loop and keeps it all live across the walk (133 spilled VGPRs); read in one piece at the top
+    // of the loop they stay live from there to their last use.
+    const FrameConst fc = tile_arg<PERSIST>(fc_arg, offsetof(SceneFrameArgs, fc));  // (ray set-up)
+    const int wave = (int)vq;                                              // the tile quadrant this wave traces now
     int tile_x, tile_y;
-    if (!xcd_tile((int)blockIdx.x, fc.width, row_count, tile_x, tile_y)) return;   // padding of the super-tile grid (whole workgroup)
+    if (!xcd_tile((int)vb, fc.width, row_count, tile_x, tile_y)) continue;  // padding of the super-tile grid
     const int col = tile_x * 16 + (wave & 1) * 8 + (lane & 7);
     const int brow = tile_y * 16 + (wave >> 1) * 8 + (lane >> 3);          // row inside this band
-    Stack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, 256};
     const bool live = col < fc.width && brow < row_count;
     const int crow = row_begin + brow;                                       // compact row of the frame
     const int row = live ? row_map[crow] : 0;
@@ -127,7 +201,6 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
         D3 dv = mk(-((double)col / width - 0.5), -((double)row / height - 0.5) * fc.aspect, fc.fov_depth);
         focal = mul3x3(fc.it, dv) * fc.focal_depth + start;
     }
-    Ctr prim = {0, 0, 0, 0};
     for (int si = 0; si < n2; ++si) {                                        // subX outer, subY inner (:1761-1763)
         const int sx = si / n, sy = si - sx * n;
         D3 ss = start, dw;
@@ -148,13 +221,17 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
         }
         Hit h;
         bool ok = false;
-        if (PKT) {
-            if (live) prim.rays++;
-            ok = root_intersect_pkt<EXTRA, true, PKT == 3 ? 2 : (PKT == 2 ? 1 : 0)>(sc, sc.extra, wnode, live, ss, dw, h, prim);     // all 64 lanes take part
-        } else if (live) {
-            prim.rays++;
-            ok = root_intersect<MODE, false, EXTRA>(sc, sc.tris, sc.extra, st, ss, dw, h, prim);
+        {
+            const DevScene sc = tile_arg<PERSIST>(sc_arg, offsetof(SceneFrameArgs, sc));   // (the walk)
+            if (PKT) {
+                if (live) prim.rays++;
+                ok = root_intersect_pkt<EXTRA, true, PKT == 3 ? 2 : (PKT == 2 ? 1 : 0)>(sc, sc.extra, wnode, live, ss, dw, h, prim);     // all 64 lanes take part
+            } else if (live) {
+                prim.rays++;
+                ok = root_intersect<MODE, false, EXTRA>(sc, sc.tris, sc.extra, st, ss, dw, h, prim);
+            }
         }
+        const FrameConst fc = tile_arg<PERSIST>(fc_arg, offsetof(SceneFrameArgs, fc));   // (shading, queue)
         if (live) {
             uint32_t color = fc.background;
             if (ok) color = (fc.flags & 1u) ? shade(fc, h.pos, h.nrm, h.color) : h.color;
@@ -201,6 +278,7 @@ __global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc, Frame
             }
         }
     }
+    }   // while (feed.next)
     if (STATS) {
         uint32_t a = wave_sum(prim.rays), b = wave_sum(prim.geom), c2 = wave_sum(prim.nodes), d2 = wave_sum(prim.leaves);
         block_stat_add(&stats[0], &stats[1], &stats[2], &stats[3], a, b, c2, d2);
@@ -357,22 +435,6 @@ __device__ __forceinline__ bool prepare_sample(const RootBox& root, D3 rs, D3 rd
 
 __device__ __forceinline__ bool prepare_sample(const DevScene& sc, D3 rs, D3 rd, SampleRay& r) { return prepare_sample(sc.root, rs, rd, r); }
 
-// A kernel argument read WHERE IT IS NEEDED, from the kernel-argument segment (byte offset `offset`), through a pointer the
-// compiler cannot see through: it loads every argument it can name at the top of the kernel and keeps it in scalar registers
-// for good -- the root box alone is 48 of them, which a rare FP64 path needs and the loop around it then pays for with
-// v_readlane / v_writelane spills.
-template <typename T>
-__device__ __forceinline__ T kernarg_late(size_t offset) {
-    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "whole 32-bit words");
-    typedef const uint32_t __attribute__((address_space(4))) CW4;
-    CW4* kp = (CW4*)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    T out;
-    uint32_t* o = reinterpret_cast<uint32_t*>(&out);
-#pragma unroll
-    for (size_t i = 0; i < sizeof(T) / 4; ++i) o[i] = kp[offset / 4 + i];
-    return out;
-}
 
 template <bool EXTRA>
 __device__ __forceinline__ bool extras_block(const DevScene& sc, D3 rs, D3 rd, Ctr& c) {
@@ -920,32 +982,48 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc
 // the candidate lists may differ in order and in which candidates a truncated list holds, which no later stage depends on.
 // LDS per wave: [levels] node words + [levels][64] 16-bit bounds, levels = 3 * b4depth + 2.
 // --------------------------------------------------------------------------------------------------
-template <bool STATS, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameConst fc, const HitRec* __restrict__ hits,
+template <bool STATS, int WAVES, bool PERSIST>
+__global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, FrameConst fc_arg, const HitRec* __restrict__ hits,
                                                     const unsigned int* __restrict__ hit_count, int cap, int levels, int tile_n2, int tile_rows,
                                                     unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
                                                     uint32_t* __restrict__ samples, unsigned int* __restrict__ work_count,
-                                                    unsigned int* __restrict__ work_list, unsigned long long* stats) {
+                                                    unsigned int* __restrict__ work_list, unsigned long long* stats,
+                                                    unsigned int* __restrict__ tile_heads, unsigned int virtual_blocks) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int32_t* wnode = reinterpret_cast<int32_t*>(lds_pipe) + (size_t)wave * ((size_t)levels * 33);   // [levels] stacked node
     // [levels][64] per-lane u bound, 16 bits: 0 = the lane's shaft misses the subtree, else 1 + the bound in 1/65534 rounded UP
     uint16_t* wbound = reinterpret_cast<uint16_t*>(wnode + levels) + lane;
     const unsigned int total = *hit_count;
-    unsigned int slot_i = blockIdx.x * 256u + (unsigned)tid;
+    uint32_t nodes = 0, leaves = 0, slabs = 0, points = 0;        // wave-level (uniform)
+    // A work item is ONE WAVE's 64 queue entries (an 8x8-pixel tile of surface points) of virtual block vb = the block of the one-
+    // workgroup-per-16x16-tile grid that k_primary filled them from.  tile_heads == nullptr: this workgroup IS virtual block
+    // blockIdx.x (one item per wave).  Otherwise the grid is persistent and every WAVE pulls items from per-XCD counters (see
+    // TileFeed): a wave that finishes a short walk starts the next tile at once instead of idling until the slowest of its
+    // workgroup's four walks ends, and the launch ends when the longest single walk does, not the longest workgroup.
+    TileFeed<PERSIST> feed(tile_heads, virtual_blocks, wave, lane);
+    unsigned int vb, vq;
+    while (feed.next(vb, vq)) {
+    // Scene and frame are read from the kernel-argument segment WHERE an iteration needs them (kernarg_late): the per-tile prologue's
+    // inputs here, the epilogue's there.  Read as plain kernel arguments the compiler hoists them -- and everything it derives from
+    // them -- out of this loop and keeps it live across the walk (25 spilled SGPRs + 54 VGPRs); read in one piece at the top of
+    // the loop they stay live from there to their uses (42 spilled VGPRs).  The walk itself only needs two pointers.
+    const DevScene sc = tile_arg<PERSIST>(sc_arg, offsetof(SceneFrameArgs, sc));      // (prologue: root box)
+    const FrameConst fc = tile_arg<PERSIST>(fc_arg, offsetof(SceneFrameArgs, fc));  // (prologue: light, width)
+    unsigned int slot_i = vb * 256u + vq * 64u + (unsigned)lane;
     if (tile_n2 > 0) {
         // tile-indexed queue (see k_primary): block b * n2 + sub-sample of this grid <-> block b of k_primary, same XCD
         int tile_x, tile_y;
-        const int pb = (int)blockIdx.x / tile_n2, si = (int)blockIdx.x - pb * tile_n2;
-        if (!xcd_tile(pb, fc.width, tile_rows, tile_x, tile_y)) return;
+        const int pb = (int)vb / tile_n2, si = (int)vb - pb * tile_n2;
+        if (!xcd_tile(pb, fc.width, tile_rows, tile_x, tile_y)) continue;
         const int tiles_x = (fc.width + 15) >> 4;
-        slot_i = ((unsigned)(tile_y * tiles_x + tile_x) * (unsigned)tile_n2 + (unsigned)si) * 256u + (unsigned)tid;
+        slot_i = ((unsigned)(tile_y * tiles_x + tile_x) * (unsigned)tile_n2 + (unsigned)si) * 256u + vq * 64u + (unsigned)lane;
     }
     HitRec rec;
     rec.sample = kInvalidHit;
     if (slot_i < total) rec = hits[slot_i];
     const bool valid = rec.sample != kInvalidHit;
-    uint32_t nodes = 0, leaves = 0, slabs = 0;                    // wave-level (uniform)
+    if (__ballot(valid) == 0ull) continue;                         // background tile
     const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
     const D3 E = valid ? mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001 : lpos * 0.5;   // ShadowMethod.cs:151
     const float R = (float)fc.light_radius * 1.00001f + 1e-30f;
@@ -981,7 +1059,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameCon
             }
             if (!found) break;
         }
-        const Bvh4Node n = sc.b4light[ni];                             // wave-uniform address: scalar loads
+        const Bvh4Node n = load_uniform(&sc_arg.b4light[ni]);          // wave-uniform address: scalar loads
         nodes++;
         const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
         const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
@@ -1001,7 +1079,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameCon
             leaves++;
             slabs += (uint32_t)cn;
             for (int q = 0; q < cn; ++q) {
-                const TriSlab s = sc.bslab[cc + q];                   // scalar load
+                const TriSlab s = load_uniform(&sc_arg.bslab[cc + q]); // scalar load
                 const bool live_q = hc && !done;
                 const int touch = shaft_touches(s, sr, live_q);
                 const bool take = live_q && touch != 0, room = count < cap;
@@ -1042,6 +1120,8 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameCon
         else nu = -1.0f;                                               // leaf-only / dead end: pop at the top of the loop
     }
     if (valid) {
+        const DevScene sc = tile_arg<PERSIST>(sc_arg, offsetof(SceneFrameArgs, sc));      // (epilogue: shadow cache, extra geometry count)
+        const FrameConst fc = tile_arg<PERSIST>(fc_arg, offsetof(SceneFrameArgs, fc));  // (epilogue: flags, sample count)
         if (umbra) {
             // fully shadowed: rayEscapeCount = 0 -> (byte)(0.0 * 255) = 0 -> ModulatePackedColor(color, 0) = opaque black
             finish_hit(sc, fc, samples, rec.sample, rec.pad[0], (fc.flags & 32u) ? 0u : samples[rec.sample], 0.0);
@@ -1055,10 +1135,9 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc, FrameCon
             work_list[atomicAdd(work_count, 1u)] = slot_i;             // the compiler aggregates this per wavefront
         }
     }
-    if (STATS) {
-        const uint32_t d2 = wave_sum(valid ? 1u : 0u);
-        block_stat_add(&stats[6], &stats[7], &stats[10], &stats[11], nodes, leaves, slabs, d2);
-    }
+    if (STATS) points += (uint32_t)__popcll(__ballot(valid));
+    }   // while (feed.next)
+    if (STATS) block_stat_add(&stats[6], &stats[7], &stats[10], &stats[11], nodes, leaves, slabs, points);
 }
 
 // undecided / escaped sample masks of a hit that moves on to the next round
@@ -1782,6 +1861,302 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
                 else if (fc.accum) fc.accum[rec_sample] += (uint32_t)esc;      // (one chunk of a > 128-sample frame)
                 else samples[rec_sample] = modulate(shaded, light_byte[esc]);
             }
+        }
+    }
+    if (STATS) {
+        uint32_t a = wave_sum(n_rays), b = wave_sum(n_cls), c = wave_sum(n_exact);
+        if (lane == 0) {
+            stat_add(&stats[4], a); stat_add(&stats[5], b);
+            stat_add(&stats[8], n_recs);             // wave-level: fp32 triangle records read
+            stat_add(&stats[9], n_items);            // wave-level: hit points processed
+            stat_add(&stats[12], b); stat_add(&stats[13], c);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// k_shadow_cls_g -- the FIRST round of the classification with the per-hit-point preparation done for a GROUP of hit points at once.
+// A first-round list holds ~7 candidates, so k_shadow_cls' lane = candidate stage (the cone planes through the surface point: ~130
+// instructions) ran at 7 of 64 lanes for every hit point, and the FP64 frame of a hit point (E', L - E', the error bounds) was
+// computed 64-fold redundantly.  Here a wave takes up to kGrpItems of its hit points together:
+//   stage 0   lane = hit point: index, queue record, list length, E' (FP64), the fp32 frame of the classification -> LDS item table
+//   fill      lane = (hit point, candidate) pair, up to 64 pairs of as many WHOLE hit points as fit: the cone-plane records -> LDS
+//   items     one hit point after the other, lanes = samples: umax, the fp32 pair loop over the hit point's records, the rare FP64
+//             path for undecided pairs, the pixel -- k_shadow_cls' code, with the hit point's constants read from the item table
+// Same arithmetic per (hit point, candidate, sample) as k_shadow_cls<.., TAIL = false>, same verdicts, same pixels; the later rounds
+// (long lists, few hit points) keep k_shadow_cls.  SR_DBG_KERNEL_SWITCH 91 runs the first round on k_shadow_cls (cross-check, A/B).
+// --------------------------------------------------------------------------------------------------
+constexpr int kGrpItems = 8;             // hit points prepared together (one lane each)
+constexpr int kGrpRecs = 64;             // candidate records staged per fill (one lane each) >= the longest first-round list
+// LDS of one wave in float4 units: records (+ one of slack: the pair loop requests the record after the one it works on) + record
+// indices + the item table (4 float4 per hit point)
+constexpr int kGrpWaveF4 = (kGrpRecs + 1) * 5 + kGrpRecs / 4 + kGrpItems * 4;
+
+template <bool EXTRA, bool STATS>
+__global__ __launch_bounds__(256) void k_shadow_cls_g(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
+                                                      const HitRec* __restrict__ hits, const unsigned int* __restrict__ hit_count,
+                                                      unsigned int count_cap, const unsigned int* __restrict__ index_list, int cap,
+                                                      const unsigned int* __restrict__ cand_count, const int32_t* __restrict__ cand,
+                                                      unsigned int* __restrict__ next_count, unsigned int next_cap,
+                                                      unsigned int* __restrict__ next_list, RoundState* __restrict__ state_out,
+                                                      unsigned int* __restrict__ last_count, unsigned int* __restrict__ last_list,
+                                                      RoundState* __restrict__ last_state,
+                                                      uint32_t* __restrict__ samples, unsigned long long* stats) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float4* wc = reinterpret_cast<float4*>(lds_pipe) + (size_t)wave * kGrpWaveF4;        // [kGrpRecs + 1][5] cone-plane records
+    int32_t* wrecidx = reinterpret_cast<int32_t*>(wc + (kGrpRecs + 1) * 5);             // [kGrpRecs] record position of every staged candidate
+    float4* witem = reinterpret_cast<float4*>(wrecidx + kGrpRecs);                      // [kGrpItems][4] per-hit-point constants
+    const int S = fc.shadow_samples;
+    uint32_t* light_byte = reinterpret_cast<uint32_t*>(reinterpret_cast<float4*>(lds_pipe) + 4 * kGrpWaveF4);   // (see k_shadow_cls)
+    for (int e = tid; e <= S; e += 256) {
+        const double frac = (double)e / (double)S;
+        uint32_t v;
+        if (fc.flags & 32u) { v = (uint32_t)(int)(frac * 254 + 1) & 0xffu; v = v ? v : 1u; }
+        else v = to_byte(frac * 255);
+        light_byte[e] = v;
+    }
+    __syncthreads();
+    const unsigned int total = min(*hit_count, count_cap);
+    const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
+    const ClsFrame cf = cls_frame(sc, fc);
+    bool valid[kPacketSlots];
+    f2 OX, OY, OZ;
+    {
+        const int j1 = lane + 64 < S ? lane + 64 : 0, j0 = lane < S ? lane : 0;
+        valid[0] = lane < S; valid[1] = lane + 64 < S;
+        OX = (f2){(float)offsets[3 * j0], (float)offsets[3 * j1]};
+        OY = (f2){(float)offsets[3 * j0 + 1], (float)offsets[3 * j1 + 1]};
+        OZ = (f2){(float)offsets[3 * j0 + 2], (float)offsets[3 * j1 + 2]};
+    }
+    uint32_t n_rays = 0, n_items = 0, n_recs = 0, n_cls = 0, n_exact = 0;
+    const unsigned int nwaves = gridDim.x * 4u;
+    const unsigned int s0 = blockIdx.x * 4u + (unsigned)wave;
+    for (unsigned int slot_g = s0; slot_g < total; slot_g += nwaves * (unsigned)kGrpItems) {
+        // ---- stage 0, lane = hit point: the wave's next kGrpItems items (slot_g, slot_g + nwaves, ...) ----
+        const unsigned int my_slot = slot_g + (unsigned)lane * nwaves;
+        const bool have_item = lane < kGrpItems && my_slot < total;
+        int my_ntri = 0;
+        if (have_item) {
+            const unsigned int h = index_list ? index_list[my_slot] : my_slot;
+            const HitRec rec = hits[h];
+            const unsigned int cc = cand_count[h];
+            const D3 E = mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001;
+            const D3 DLd = lpos - E;
+            const float efx = (float)(E.x - sc.root.centre[0]), efy = (float)(E.y - sc.root.centre[1]), efz = (float)(E.z - sc.root.centre[2]);
+            const float dlx = (float)DLd.x, dly = (float)DLd.y, dlz = (float)DLd.z;
+            const float dmax = __builtin_amdgcn_sqrtf(dlx * dlx + dly * dly + dlz * dlz) * 1.0001f + cf.R;   // an upper bound is all it has to be
+            const uint32_t shaded = (fc.flags & 32u) ? 0u : samples[rec.sample];
+            my_ntri = (int)(cc & 0xffffu);
+            witem[lane * 4 + 0] = make_float4(efx, efy, efz, dlx);
+            witem[lane * 4 + 1] = make_float4(dly, dlz, dmax, 0.0f);
+            witem[lane * 4 + 2] = make_float4(__uint_as_float(h), __uint_as_float(rec.sample), __uint_as_float(rec.pad[0]), __uint_as_float(cc));
+            witem[lane * 4 + 3] = make_float4(__uint_as_float(shaded), 0.0f, 0.0f, 0.0f);
+        }
+        int incl = my_ntri;                                               // inclusive prefix sum of the list lengths over the group's lanes
+#pragma unroll
+        for (int d = 1; d < kGrpItems; d <<= 1) {
+            const int v = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += v;
+        }
+        const int excl = incl - my_ntri;
+        const unsigned int left = (total - slot_g + nwaves - 1u) / nwaves;
+        const int nitems = (int)min((unsigned)kGrpItems, left);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int ja = 0;
+        while (ja < nitems) {
+            // ---- as many whole hit points as fit kGrpRecs records ----
+            const int base = __builtin_amdgcn_readlane(excl, ja);
+            int jb = ja + 1;
+            while (jb < nitems && __builtin_amdgcn_readlane(incl, jb) - base <= kGrpRecs) ++jb;
+            const int npairs = __builtin_amdgcn_readlane(incl, jb - 1) - base;
+            // ---- fill, lane = (hit point, candidate): cone planes through E' and their margins (see k_shadow_cls) ----
+            if (lane < npairs) {
+                int jj = ja, ofs = 0;
+                for (int j = ja + 1; j < jb; ++j) {
+                    const int o = __builtin_amdgcn_readlane(excl, j) - base;
+                    if (lane >= o) { jj = j; ofs = o; }
+                }
+                const float4 i0 = witem[jj * 4 + 0], i1 = witem[jj * 4 + 1], i2 = witem[jj * 4 + 2];
+                const float efx = i0.x, efy = i0.y, efz = i0.z, dlx = i0.w, dly = i1.x, dlz = i1.y, dmax = i1.z;
+                const unsigned int hj = __float_as_uint(i2.x);
+                const int32_t ent = cand[(size_t)hj * cap + (lane - ofs)];
+                const TriSlab slab = sc.bslab[ent];
+                const f2 edx = {efx, dlx}, edy = {efy, dly}, edz = {efz, dlz};
+                const f2 cn = {-slab.d, 0.0f}, c1 = {-slab.c1, 0.0f}, c2 = {-slab.c2, 0.0f}, c3 = {-slab.c3, 0.0f};
+                const f2 N = pk_fma(splat(slab.n[0]), edx, pk_fma(splat(slab.n[1]), edy, pk_fma(splat(slab.n[2]), edz, cn)));    // (G0, n.(L - E'))
+                const f2 P = pk_fma(splat(slab.m1[0]), edx, pk_fma(splat(slab.m1[1]), edy, pk_fma(splat(slab.m1[2]), edz, c1)));  // (K0_1, .)
+                const f2 Q = pk_fma(splat(slab.m2[0]), edx, pk_fma(splat(slab.m2[1]), edy, pk_fma(splat(slab.m2[2]), edz, c2)));
+                const f2 T = pk_fma(splat(slab.m3[0]), edx, pk_fma(splat(slab.m3[1]), edy, pk_fma(splat(slab.m3[2]), edz, c3)));
+                const float G0 = N.x;
+                float4 W[3];
+                const float K0[3] = {P.x, Q.x, T.x};
+                const float* mm[3] = {slab.m1, slab.m2, slab.m3};
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const float wx = __builtin_fmaf(K0[e], slab.n[0], -(G0 * mm[e][0]));
+                    const float wy = __builtin_fmaf(K0[e], slab.n[1], -(G0 * mm[e][1]));
+                    const float wz = __builtin_fmaf(K0[e], slab.n[2], -(G0 * mm[e][2]));
+                    W[e] = make_float4(wx, wy, wz, __builtin_fmaf(wx, dlx, __builtin_fmaf(wy, dly, wz * dlz)));
+                }
+                const float kmax = fmaxf(fmaxf(fabsf(P.x), fabsf(Q.x)), fabsf(T.x));
+                const float mc = dmax * (kU24 * (15.0f * cf.s0 + 16.0f * (kmax + fabsf(G0))) + 1e-9f);
+                float4* w = wc + lane * 5;
+                w[0] = make_float4(N.y, slab.n[0], slab.n[1], slab.n[2]);
+                w[1] = make_float4(W[0].w, W[0].x, W[0].y, W[0].z);
+                w[2] = make_float4(W[1].w, W[1].x, W[1].y, W[1].z);
+                w[3] = make_float4(W[2].w, W[2].x, W[2].y, W[2].z);
+                w[4] = make_float4(G0, G0 <= -cf.a0 ? mc : 1e30f, G0 >= cf.a0 ? -1e30f : mc, 0.0f);
+                wrecidx[lane] = ent;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            n_recs += (uint32_t)npairs;
+            // ---- the hit points of this fill, one after the other: lanes = samples ----
+            for (int j = ja; j < jb; ++j) {
+                const int off_local = __builtin_amdgcn_readlane(excl, j) - base;
+                const float4 i0 = witem[j * 4 + 0], i1 = witem[j * 4 + 1], i2 = witem[j * 4 + 2], i3 = witem[j * 4 + 3];
+                const auto uni = [](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
+                const float efx = uni(i0.x), efy = uni(i0.y), efz = uni(i0.z), dlx = uni(i0.w), dly = uni(i1.x), dlz = uni(i1.y), dmax = uni(i1.z);
+                const unsigned int h = __float_as_uint(uni(i2.x)), rec_sample = __float_as_uint(uni(i2.y)), rec_cell = __float_as_uint(uni(i2.z)), cc = __float_as_uint(uni(i2.w));
+                const uint32_t shaded = __float_as_uint(uni(i3.x));
+                n_items++;
+                const int ntri = (int)(cc & 0xffffu);
+                const bool truncated = (cc & kTruncated) != 0;
+                const bool work = ntri > 0 || truncated;      // an empty, complete list: every sample escapes
+                const float a1 = 20.0f * kU24 * dmax, glo = 16.0f * a1;
+                const float pm = 5e-7f * (cf.s0 + dmax);                        // position error bound of E' + u D_i in fp32 (>= 4u (|E'| + u |D|))
+                // ---- per (hit point, sample): state + umax ----
+                bool alive[kPacketSlots], escaped[kPacketSlots];
+#pragma unroll
+                for (int q = 0; q < kPacketSlots; ++q) {
+                    alive[q] = false;
+                    escaped[q] = valid[q];
+                    if (valid[q]) {
+                        n_rays++;
+                        bool blocked = false;
+                        if (EXTRA) {
+                            const HitRec rq = hits[h];
+                            const D3 Eq = mk(rq.pos[0], rq.pos[1], rq.pos[2]) + mk(rq.nrm[0], rq.nrm[1], rq.nrm[2]) * 0.001;
+                            Ctr cx = {0, 0, 0, 0}; const int sj = lane + 64 * q; const D3 rs = lpos + mk(offsets[3 * sj], offsets[3 * sj + 1], offsets[3 * sj + 2]);
+                            blocked = extras_block<EXTRA>(sc, rs, Eq - rs, cx);
+                        }
+                        if (blocked) escaped[q] = false;
+                        else alive[q] = work;
+                    }
+                }
+                f2 UM;
+                {
+                    const float sx = cf.hbx - 4.0f * pm, sy = cf.hby - 4.0f * pm, sz = cf.hbz - 4.0f * pm;
+                    const bool ein = fabsf(efx) < sx && fabsf(efy) < sy && fabsf(efz) < sz;
+                    const f2 dxv = OX + splat(dlx), dyv = OY + splat(dly), dzv = OZ + splat(dlz);
+                    const f2 rx = {__builtin_amdgcn_rcpf(dxv.x), __builtin_amdgcn_rcpf(dxv.y)}, ry = {__builtin_amdgcn_rcpf(dyv.x), __builtin_amdgcn_rcpf(dyv.y)},
+                             rz = {__builtin_amdgcn_rcpf(dzv.x), __builtin_amdgcn_rcpf(dzv.y)};
+                    const f2 tx = ((f2){__builtin_copysignf(sx, dxv.x), __builtin_copysignf(sx, dxv.y)} - splat(efx)) * rx;
+                    const f2 ty = ((f2){__builtin_copysignf(sy, dyv.x), __builtin_copysignf(sy, dyv.y)} - splat(efy)) * ry;
+                    const f2 tz = ((f2){__builtin_copysignf(sz, dzv.x), __builtin_copysignf(sz, dzv.y)} - splat(efz)) * rz;
+                    const f2 ut = {fminf(fminf(fminf(tx.x, ty.x), tz.x), 0.999999f), fminf(fminf(fminf(tx.y, ty.y), tz.y), 0.999999f)};
+                    const f2 px = pk_fma(ut, dxv, splat(efx)), py = pk_fma(ut, dyv, splat(efy)), pz = pk_fma(ut, dzv, splat(efz));
+                    const bool ok0 = ein && ut.x > 0.0f && fabsf(px.x) < cf.hbx - pm && fabsf(py.x) < cf.hby - pm && fabsf(pz.x) < cf.hbz - pm;
+                    const bool ok1 = ein && ut.y > 0.0f && fabsf(px.y) < cf.hbx - pm && fabsf(py.y) < cf.hby - pm && fabsf(pz.y) < cf.hbz - pm;
+                    UM = (f2){ok0 ? ut.x : -1.0f, ok1 ? ut.y : -1.0f};
+                }
+                const float hbm = cf.a0 + a1;
+                bool have = __any(alive[0] || alive[1]);
+                const f4* wc4 = reinterpret_cast<const f4*>(wc) + (size_t)off_local * 5;
+                for (int cbase = 0; cbase < ntri && have; cbase += 32) {          // (32 candidates per "undecided" mask)
+                    const int nc = min(32, ntri - cbase);
+                    const f4* rc4 = wc4 + (size_t)cbase * 5;
+                    uint32_t unc[kPacketSlots] = {0u, 0u};
+                    const unsigned long long al0 = __ballot(alive[0]), al1 = __ballot(alive[1]);
+                    unsigned long long blk0 = 0ull, blk1 = 0ull;                  // samples some candidate of this chunk blocks
+                    int k = 0;
+                    unsigned long long am0 = 0ull, am1 = 0ull;                    // samples still undecided
+                    f4 nA = rc4[0], nB1 = rc4[1], nB2 = rc4[2], nB3 = rc4[3], nF = rc4[4];
+                    for (; k < nc && have; ++k) {
+                        const f4 A = nA, B1 = nB1, B2 = nB2, B3 = nB3, F = nF;
+                        nA = rc4[k * 5 + 5]; nB1 = rc4[k * 5 + 6]; nB2 = rc4[k * 5 + 7]; nB3 = rc4[k * 5 + 8]; nF = rc4[k * 5 + 9];
+                        const auto plane = [&](const f4& r) {
+                            const f2 cx = {r.x, r.y}, yz = {r.z, r.w};
+                            return pk_fma_hi(cx, OX, pk_fma_lo(yz, OY, pk_fma_hi_addlo(yz, OZ, cx)));
+                        };
+                        const f2 g1 = plane(A), c1 = plane(B1), c2 = plane(B2), c3 = plane(B3);
+                        const f2 hb = pk_fma(UM, g1, splat(F.x));                 // G at u = umax_i: > 0 <=> the crossing comes earlier
+                        const f2 cmin = {fminf(fminf(c1.x, c2.x), c3.x), fminf(fminf(c1.y, c2.y), c3.y)};
+                        const f2 s3 = g1 - splat(glo), s1 = cmin - splat(F.y), s4 = hb - splat(hbm);
+                        const f2 tm0 = splat(-F.z) - cmin, bfv = splat(-glo) - g1;
+                        const float tblk0 = fminf(fminf(s1.x, s3.x), s4.x), tblk1 = fminf(fminf(s1.y, s3.y), s4.y);
+                        const float tall0 = fmaxf(fmaxf(fminf(tm0.x, s3.x), bfv.x), tblk0), tall1 = fmaxf(fmaxf(fminf(tm0.y, s3.y), bfv.y), tblk1);
+                        unc[0] = shift_in_not_positive(unc[0], tall0);
+                        unc[1] = shift_in_not_positive(unc[1], tall1);
+                        blk0 |= __ballot(tblk0 > 0.0f);
+                        blk1 |= __ballot(tblk1 > 0.0f);
+                        am0 = al0 & ~blk0; am1 = al1 & ~blk1;
+                        if (STATS) n_cls += (uint32_t)((am0 >> lane) & 1ull) + (uint32_t)((am1 >> lane) & 1ull);
+                        have = (am0 | am1) != 0ull;
+                        asm volatile("" : "+v"(nA), "+v"(nB1), "+v"(nB2), "+v"(nB3), "+v"(nF));
+                    }
+                    if (k > 0) { unc[0] = __brev(unc[0]) >> (32 - k); unc[1] = __brev(unc[1]) >> (32 - k); }   // bit j = candidate j
+                    if (((blk0 >> lane) & 1ull) != 0ull && alive[0]) { alive[0] = false; escaped[0] = false; }
+                    if (((blk1 >> lane) & 1ull) != 0ull && alive[1]) { alive[1] = false; escaped[1] = false; }
+                    // ---- the undecided pairs of the samples no candidate blocked so far: the reference's FP64 arithmetic (rare) ----
+                    if (__any((alive[0] && unc[0] != 0u) || (alive[1] && unc[1] != 0u))) {
+                        const HitRec rq = hits[h];
+                        const D3 E = mk(rq.pos[0], rq.pos[1], rq.pos[2]) + mk(rq.nrm[0], rq.nrm[1], rq.nrm[2]) * 0.001;
+#pragma unroll 1
+                        for (int q = 0; q < kPacketSlots; ++q) {
+                            uint32_t m = (q ? alive[1] : alive[0]) ? (q ? unc[1] : unc[0]) : 0u;
+                            if (m) {
+                                const int sj = lane + 64 * q;
+                                const D3 rs = lpos + mk(offsets[3 * sj], offsets[3 * sj + 1], offsets[3 * sj + 2]);
+                                SampleRay ray;
+                                const RootBox root = kernarg_late<RootBox>(offsetof(DevScene, root));   // (the scene is the kernel's first argument)
+                                bool is_alive = prepare_sample(root, rs, E - rs, ray);  // false: the ray misses the root box, nothing can block it
+                                bool blocked = false;
+                                while (is_alive && m) {
+                                    const int kk = __ffs((int)m) - 1;
+                                    m &= m - 1u;
+                                    if (STATS) n_exact++;
+                                    if (tri_blocks(sc.btris[wrecidx[off_local + cbase + kk]].p, ray, root.lo, root.hi)) { is_alive = false; blocked = true; }
+                                }
+                                if (!is_alive) {
+                                    if (q) { alive[1] = false; if (blocked) escaped[1] = false; }
+                                    else { alive[0] = false; if (blocked) escaped[0] = false; }
+                                }
+                            }
+                        }
+                    }
+                    have = __any(alive[0] || alive[1]);
+                }
+                if (have && truncated) {
+                    // the list ran out before the shaft did and some sample is still undecided: next round, or the exact fallback
+                    const unsigned long long a0m = __ballot(alive[0]), a1m = __ballot(alive[1]), e0 = __ballot(escaped[0]), e1m = __ballot(escaped[1]);
+                    if (lane == 0) {
+                        unsigned int slot = next_count ? atomicAdd(next_count, 1u) : 0xffffffffu;
+                        RoundState o;
+                        o.alive[0] = a0m; o.alive[1] = a1m; o.escaped[0] = e0; o.escaped[1] = e1m;
+                        if (slot < next_cap) {
+                            next_list[slot] = h;
+                            state_out[slot] = o;
+                        } else {
+                            const unsigned int fi = atomicAdd(last_count, 1u);    // the fallback only traces the undecided samples
+                            last_list[fi] = h;
+                            last_state[fi] = o;
+                        }
+                    }
+                } else {
+                    const int esc = (int)__popcll(__ballot(escaped[0])) + (int)__popcll(__ballot(escaped[1]));
+                    if (lane == 0) {                                               // finish_hit with the tabulated byte
+                        if (fc.flags & 32u) sc.shadow_cache[rec_cell] = (uint8_t)light_byte[esc];
+                        else if (fc.accum) fc.accum[rec_sample] += (uint32_t)esc;      // (one chunk of a > 128-sample frame)
+                        else samples[rec_sample] = modulate(shaded, light_byte[esc]);
+                    }
+                }
+            }
+            ja = jb;
+            __builtin_amdgcn_wave_barrier();                              // (the next fill overwrites the records)
         }
     }
     if (STATS) {
@@ -2819,18 +3194,32 @@ static int pipe_stack_levels(const DevScene& sc, int mode) {
     return 1;
 }
 
+// the tile kernels' work distribution (TileFeed): counters[kHeadsPrimary ..] / [kHeadsShaft ..] are the per-XCD heads of k_primary /
+// k_shaft_pkt4, zeroed with the band's other counters.  A launch goes persistent when its tile grid is larger than the resident grid
+// (small frames keep one workgroup per tile: nothing to balance, no atomics); SR_DBG_KERNEL_SWITCH 81 keeps every launch direct
+constexpr int kHeadsPrimary = 64, kHeadsShaft = kHeadsPrimary + 8 * kTileHeadStride, kCounterWords = kHeadsShaft + 8 * kTileHeadStride;
+static unsigned tile_grid(const PipelineLaunch& L, unsigned virtual_blocks, int wgs_per_cu, unsigned int* heads, unsigned int** heads_out) {
+    const unsigned resident = (unsigned)(L.persistent_blocks / 8 * wgs_per_cu);
+    const bool persistent = virtual_blocks > resident && L.fc.debug != 81 && (virtual_blocks & 7u) == 0u;
+    *heads_out = persistent ? heads : nullptr;
+    return persistent ? resident : virtual_blocks;
+}
+
 template <int MODE, bool EXTRA, bool SUB, int PKT>
 static hipError_t launch_primary_p(const PipelineLaunch& L, int row_begin, int row_count, uint32_t* samples, int pad_tiles) {
-    // 1-D grid over the padded super-tile grid (see the tile order in k_primary)
-    dim3 grid((unsigned)xcd_tile_grid(L.fc.width, row_count));
+    // 1-D grid over the padded super-tile grid (see the tile order in k_primary), or the resident grid pulling its tiles (TileFeed)
+    const unsigned vblocks = (unsigned)xcd_tile_grid(L.fc.width, row_count);
+    unsigned int* heads;
+    dim3 grid(tile_grid(L, vblocks, SUB ? 5 : 6, L.counters + kHeadsPrimary, &heads));
+    if (heads && L.fc.debug != 82) { heads = nullptr; grid = dim3(vblocks); }      // (k_primary's persistent form is opt-in: SR_DBG_KERNEL_SWITCH 82)
     const int levels = PKT >= 2 ? 3 * L.sc.b4depth + 2 : pipe_stack_levels(L.sc, MODE);
     size_t lds = PKT ? (size_t)levels * 4 * 4 : (size_t)levels * 256 * 4;
-    if (L.stats)
-        hipLaunchKernelGGL((k_primary<MODE, EXTRA, true, SUB, PKT>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
-                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats, pad_tiles, levels);
-    else
-        hipLaunchKernelGGL((k_primary<MODE, EXTRA, false, SUB, PKT>), grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
-                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats, pad_tiles, levels);
+    const auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, L.stream, L.sc, L.fc, L.row_map, row_begin, row_count,
+                           samples, (HitRec*)L.hits, L.counters, L.bounce_levels, L.bounce_nlev, L.stats, pad_tiles, levels, heads, vblocks);
+    };
+    if (heads) { if (L.stats) go(k_primary<MODE, EXTRA, true, SUB, PKT, true>); else go(k_primary<MODE, EXTRA, false, SUB, PKT, true>); }
+    else { if (L.stats) go(k_primary<MODE, EXTRA, true, SUB, PKT, false>); else go(k_primary<MODE, EXTRA, false, SUB, PKT, false>); }
     return hipGetLastError();
 }
 
@@ -2912,13 +3301,17 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                 size_t lds = ((size_t)lv4 * 4 + (size_t)lv4 * 64 * 2) * 4;
                 const int tn2 = L.tile_queue_n2, trows = L.tile_queue_rows;
                 if (tn2 > 0) blocks = (unsigned)(xcd_tile_grid(L.fc.width, trows) * tn2);      // the grid of k_primary (x sub-samples)
+                unsigned int* heads;
+                const unsigned vblocks = blocks;
+                blocks = tile_grid(L, vblocks, 6, L.counters + kHeadsShaft, &heads);          // ... or the resident grid pulling its tiles
                 const auto go = [&](auto kern) {
-                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats);
+                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats, heads, vblocks);
                 };
                 // 6 waves/SIMD (85 VGPRs): 5.16 ms on the headline frame; 7 waves (72 VGPRs, spills in the node step) 5.44; 5 waves 5.61
                 // ((near, far) planes in the light-ordered copy, as in the camera-ordered one, were measured: fewer instructions, more spills at
                 //  this kernel's register budget -- 5.17 -> 5.30 ms; 5.49 ms at 5 waves/SIMD)
-                if (L.stats) go(k_shaft_pkt4<true, 6>); else go(k_shaft_pkt4<false, 6>);
+                if (heads) { if (L.stats) go(k_shaft_pkt4<true, 6, true>); else go(k_shaft_pkt4<false, 6, true>); }
+                else { if (L.stats) go(k_shaft_pkt4<true, 6, false>); else go(k_shaft_pkt4<false, 6, false>); }
             } else if (first && !(L.per_lane_shaft & 1)) {
                 // round 1 on the binary tree (cross-check): one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
                 size_t lds = ((size_t)levels * 4 + (size_t)levels * 64 * 2) * 4;
@@ -2968,7 +3361,14 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                 const auto args = [&](auto kern) {
                     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_c, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
                 };
-                if (first) { if (L.stats) args(k_shadow_cls<EXTRA, true, false>); else args(k_shadow_cls<EXTRA, false, false>); }
+                if (first && L.fc.debug != 91 && cap <= kGrpRecs) {
+                    // first round: the per-hit-point preparation done for groups of hit points (k_shadow_cls_g)
+                    const size_t lds_g = 4 * (size_t)kGrpWaveF4 * sizeof(float4) + (64 * kPacketSlots + 1) * sizeof(uint32_t);
+                    const auto args_g = [&](auto kern) {
+                        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_g, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, cap, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
+                    };
+                    if (L.stats) args_g(k_shadow_cls_g<EXTRA, true>); else args_g(k_shadow_cls_g<EXTRA, false>);
+                } else if (first) { if (L.stats) args(k_shadow_cls<EXTRA, true, false>); else args(k_shadow_cls<EXTRA, false, false>); }
                 else { if (L.stats) args(k_shadow_cls<EXTRA, true, true>); else args(k_shadow_cls<EXTRA, false, true>); }
             } else if (L.stats) hipLaunchKernelGGL((k_shadow_test<EXTRA, true>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
             else hipLaunchKernelGGL((k_shadow_test<EXTRA, false>), dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, L.offsets, (const HitRec*)L.hits, t_count, count_cap, t_list, st_in, cap, first ? 1 : 0, L.round_cand_count[round], L.round_cand[round], next_count, next_cap, next_list, st_out, fb_count, L.fallback, (RoundState*)L.fallback_state, samples, L.stats);
@@ -3013,10 +3413,8 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
         int row_count = std::min(L.band_rows, L.row_limit - row_begin);
         uint32_t* samples = (n2 == 1) ? L.pixels : L.samples;
         hipError_t e;
-        if (shadows || L.fc.max_bounces > 0) {
-            e = hipMemsetAsync(L.counters, 0, 16 * sizeof(unsigned int), L.stream);
-            if (e != hipSuccess) return e;
-        }
+        e = hipMemsetAsync(L.counters, 0, kCounterWords * sizeof(unsigned int), L.stream);   // the band's counters and both kernels' tile heads
+        if (e != hipSuccess) return e;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (L.get_events) L.get_events(L.user, K_PRIMARY, &e0, &e1);
         if (e0) { e = hipEventRecord(e0, L.stream); if (e != hipSuccess) return e; }
@@ -3106,6 +3504,7 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
             if ((e = hipGetLastError()) != hipSuccess) return e;
             if ((e = hipMemcpyAsync(L.counters + 14, L.counters, 4, hipMemcpyDeviceToDevice, L.stream)) != hipSuccess) return e;
             if ((e = hipMemcpyAsync(L.counters, L.counters + 13, 4, hipMemcpyDeviceToDevice, L.stream)) != hipSuccess) return e;
+            if ((e = hipMemsetAsync(L.counters + kHeadsShaft, 0, 8 * kTileHeadStride * sizeof(unsigned int), L.stream)) != hipSuccess) return e;
             PipelineLaunch G = L;
             G.hits = L.static_hits;
             if (L.primary_stats_only) G.stats = nullptr;
@@ -3130,6 +3529,7 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
                     T.fc.shadow_samples = std::min(64 * kPacketSlots, S - c * 64 * kPacketSlots);
                     T.offsets = L.offsets + (size_t)c * 64 * kPacketSlots * 3;
                     if (c > 0 && (e = hipMemsetAsync(L.counters + 1, 0, 15 * sizeof(unsigned int), L.stream)) != hipSuccess) return e;
+                    if (c > 0 && (e = hipMemsetAsync(L.counters + kHeadsShaft, 0, 8 * kTileHeadStride * sizeof(unsigned int), L.stream)) != hipSuccess) return e;
                 }
                 // primary rays through the reference tree / brute force, shadow rays on the own BVH (sr_api.cpp decides when that is allowed)
                 if (MODE != MODE_BVH && L.shadows_on_bvh) e = launch_shadow_t<MODE_BVH, EXTRA>(T, samples, max_hits);
@@ -3176,5 +3576,6 @@ int pipeline_round_cap(int round) { return kRoundCap[round]; }   // default list
 int pipeline_round_cap_max(int round) { return round == 0 ? 64 : 1024; }
 int pipeline_bounce_lds_levels() { return kBounceLdsLevels; }
 size_t pipeline_round_state_bytes() { return sizeof(RoundState); }
+size_t pipeline_counter_bytes() { return (size_t)kCounterWords * sizeof(unsigned int); }
 
 }  // namespace sr

@@ -601,6 +601,23 @@ __device__ __forceinline__ void child_slabs(const Bvh4Child& ch, f2 I01, f2 I20,
     a = fmaxf(fmaxf(nx, ny), nz);
     b = fminf(fminf(fx, fy), fz);
 }
+// A record at a WAVE-UNIFORM address, read through the constant address space: scalar loads (s_load_dwordxN through the scalar cache)
+// whatever the compiler can or cannot prove about the stores around it.  Left to itself it only uses scalar loads for memory it can
+// show is not written between the kernel's entry and the load; inside a loop that also stores (the persistent tile loops of
+// k_primary / k_shaft_pkt4) that proof fails and a 128-byte node arrives as vector loads + 32 v_readfirstlane.  Only for memory the
+// kernel never writes (tree nodes, TriSlab / CamCone records).
+template <class T>
+__device__ __forceinline__ T load_uniform(const T* p) {
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "whole 32-bit words");
+    typedef const uint32_t __attribute__((address_space(4))) CW4;
+    CW4* w = (CW4*)(const void*)p;
+    T out;
+    uint32_t* o = reinterpret_cast<uint32_t*>(&out);
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) o[i] = w[i];
+    return out;
+}
+
 // value k of four with a wave-uniform k (scalar selects / v_cndmask with scalar conditions: no indexed registers, no scratch)
 template <class T> __device__ __forceinline__ T pick4(int k, T a, T b, T c, T d) { return k == 0 ? a : (k == 1 ? b : (k == 2 ? c : d)); }
 
@@ -627,7 +644,7 @@ __device__ bool bvh4_packet_nearest(const DevScene& sc, int32_t* wnode, bool liv
     const bool counter_lane = act && (__ffsll((long long)__ballot(act)) - 1) == (int)(threadIdx.x & 63u);
     if (__ballot(act) != 0ull) {
         for (;;) {
-            const Bvh4Node n = sc.b4cam[ni];                           // wave-uniform address: scalar loads
+            const Bvh4Node n = load_uniform(&sc.b4cam[ni]);            // wave-uniform address: scalar loads
             if (counter_lane) c.nodes++;                               // (per WAVE: 128-byte nodes fetched)
             float t0, x0, t1, x1, t2, x2, t3, x3;
             child_slabs<KNOWN>(n.ch[0], I01, I20, I12, B0, B1, B2, t0, x0);
@@ -645,7 +662,7 @@ __device__ bool bvh4_packet_nearest(const DevScene& sc, int32_t* wnode, bool liv
                 for (int q = cc; q < cc + cn; ++q) {
                     bool cand = hc;
                     if (FILTER) {
-                        const CamCone cm = sc.bcam[q];                               // scalar load
+                        const CamCone cm = load_uniform(&sc.bcam[q]);                // scalar load
                         cand = hc && !cone_rejects(cm, dxx, dyy, dzz, dl);
                     }
                     if (hc_first) c.geom++;
