@@ -361,7 +361,7 @@ def main():
     ap.add_argument("--dbg", action="append", default=[], metavar="KEY=VALUE", help="sr_debug_set hook, e.g. --dbg 1=16 (SR_DBG_ROUND_CAP0 = 16)")
     ap.add_argument("--in-library", action="store_true", help="single process: --gpus N devices behind sr_create_multi instead of one rank per GPU")
     ap.add_argument("--same-device", action="store_true", help="with --in-library: list device 0 N times (rehearsal on a one-GPU box)")
-    ap.add_argument("--prelude-s", type=float, default=2.0, help="untimed seconds of continuous frames before the timed region (lets GPU-busy samplers see the GPU phase)")
+    ap.add_argument("--prelude-s", type=float, default=6.0, help="untimed seconds of continuous frames before the timed region (lets GPU-busy samplers see the GPU phase)")
     ap.add_argument("--verify", action="store_true", help="after timing: rank 0 re-renders the whole frame alone and compares it with the one that arrived on the host")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for single-GPU rehearsals)")
     ap.add_argument("--no-verify", action="store_true", help="N > 1 verifies the gathered frame against a single-GPU render by default; this turns it off")

@@ -373,7 +373,11 @@ enum {
                                     queue order (no per-level ray sort); 61 the camera-ordered node copy keeps (lo, hi) planes; 71 no facing
                                     partition (the packet walks see every record of a leaf); 7 counts umbra decisions of the private shaft walk;
                                     32 a mirror-bounce level as ONE kernel (k_bounce) instead of prepare / walk / finish; 100 + T: the walk kernel
-                                    fetches new rays at T busy lanes (default 24); 200 + K: K stack levels per lane in LDS (default 24)     */
+                                    fetches new rays at T busy lanes (default 24); 200 + K: K stack levels per lane in LDS (default 24);
+                                    81 the tile kernels with one workgroup per 16x16 tile (no persistent grid); 82 k_primary on the persistent grid
+                                    too (its loop form spills registers: opt-in); 84 the persistent shaft walk hands its tiles out in natural order
+                                    (no longest-first lists); 830 + n: n resident workgroups per CU for it; 840 + q: a walk is long at q / 4 x the
+                                    mean; 91 the first classification round on k_shadow_cls instead of k_shadow_cls_g                      */
     SR_DBG_KERNEL_TIMING  = 7,   /* > 0: record a HIP event pair around every launch (sr_kernel_times); default off           */
     SR_DBG_EXACT_SHADOW_TESTS = 8, /* > 0: k_shadow_test decides every (sample, triangle) pair with the FP64 arithmetic (no
                                     fp32 classification): an independent schedule of the same result, kept as a cross-check */

@@ -131,11 +131,14 @@ struct sr_scene {
     struct BandScratch {
         DBuf hits, hits2, bounce_levels, bounce_nlev, bounce_prep, bounce_res, bounce_stack, samples, counters, fallback, fallback_state, fallback_rays, fallback_ovf, ray_sort, ray_sort_temp;
         DBuf accum;                        // escape counts per sample index of a chunked (> 128 samples) shadow stage; zero between frames
+        DBuf tile_cost, tile_order;        // walk length per 8x8 tile of the last shaft launch / the next one's longest-first lists
+        unsigned long long tile_order_tag = 0;   // the tile grid tile_order was made for (0: none)
         DBuf rlist[sr::kShaftRounds], rstate[sr::kShaftRounds], rcount[sr::kShaftRounds], rcand[sr::kShaftRounds];
         hipStream_t stream = nullptr;
         hipEvent_t  done = nullptr;
         bool used_last_frame = false;
         void release() {
+            tile_cost.release(); tile_order.release(); tile_order_tag = 0;
             DBuf* b[] = {&hits, &hits2, &bounce_levels, &bounce_nlev, &bounce_prep, &bounce_res, &bounce_stack, &samples, &counters, &fallback, &fallback_state, &fallback_rays, &fallback_ovf, &ray_sort, &ray_sort_temp, &accum};
             for (DBuf* x : b) x->release();
             for (int r = 0; r < sr::kShaftRounds; ++r) { rlist[r].release(); rstate[r].release(); rcount[r].release(); rcand[r].release(); }
@@ -657,6 +660,14 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
             SR_HIP(B.ray_sort.reserve((size_t)band_samples * 4 * 4));
             SR_HIP(B.ray_sort_temp.reserve(sr::ray_sort_temp_bytes((unsigned)band_samples)));
         }
+        // (one band per part-frame pipeline: a second band would walk other tiles with the first one's lists)
+        const bool order_tiles = shaft && band_rows >= rows_half;
+        if (order_tiles) {
+            const size_t bytes = sr::pipeline_tile_items(fc.width, (int)band_rows, (int)n2) * 4;
+            if (bytes > B.tile_cost.cap) B.tile_order_tag = 0;
+            SR_HIP(B.tile_cost.reserve(bytes));
+            SR_HIP(B.tile_order.reserve(bytes));
+        }
         if (shaft) {
             SR_HIP(B.fallback.reserve((size_t)band_samples * 4));
             SR_HIP(B.fallback_state.reserve((size_t)band_samples * sr::pipeline_round_state_bytes()));
@@ -708,6 +719,9 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.bounce_stack = bounce_pipe ? (int32_t*)B.bounce_stack.p : nullptr;
         P.bounce_stack_bytes = bounce_pipe ? B.bounce_stack.cap : 0;
         P.counters = (unsigned int*)B.counters.p;
+        P.tile_cost = order_tiles ? (unsigned int*)B.tile_cost.p : nullptr;
+        P.tile_order = order_tiles ? (unsigned int*)B.tile_order.p : nullptr;
+        P.tile_order_tag = order_tiles ? &B.tile_order_tag : nullptr;
         P.static_hits = static_shadows ? s->d_static_hits.p : nullptr;
         P.static_claim = static_shadows ? (unsigned long long*)s->d_static_claim.p : nullptr;
         P.static_concurrency = f->concurrency;

@@ -106,6 +106,12 @@ struct PipelineLaunch {
     int32_t     per_lane_shaft;   // bit 0: k_shaft (private walks) for the first round instead of k_shaft_pkt, bit 1: for the later rounds instead of k_shaft_coop (cross-checks)
     bool        exact_shadow_tests; // k_shadow_test (every pair in FP64) instead of k_shadow_cls (fp32 classification first)
     unsigned long long* stats;  // device [8] or nullptr
+    // longest-first order of the persistent shaft kernel's tiles: k_shaft_pkt4 leaves every 8x8 tile's walk length in tile_cost, k_tile_order
+    // turns them into per-XCD lists (longest walks first) for the NEXT frame with the same tile grid; `tile_order_tag` is host state of the
+    // scratch set: the grid the lists in tile_order were made for (0: none).  All three nullptr: natural order
+    unsigned int* tile_cost;
+    unsigned int* tile_order;
+    unsigned long long* tile_order_tag;
     hipStream_t stream;
     void (*get_events)(void* user, int kernel_id, hipEvent_t* start, hipEvent_t* stop);   // optional per-launch timing
     // optional: called when every kernel of a row band has been enqueued on `stream` -- compact rows [row_begin, row_begin + row_count)
@@ -134,6 +140,7 @@ int pipeline_round_cap_max(int round);
 int pipeline_bounce_lds_levels();      // stack levels per lane k_bounce_walk keeps in LDS (deeper ones live in PipelineLaunch::bounce_stack)
 size_t pipeline_round_state_bytes();
 size_t pipeline_counter_bytes();
+size_t pipeline_tile_items(int width, int rows, int n2);
 
 // Own BVH built on the device (sr_lbvh.hip).  Inputs in TriangleIndex order, outputs caller-allocated (n entries each).
 hipError_t gather_records_device(int n, const unsigned int* d_order, const Rec128* d_tris, Rec128* d_btris, const TriSlab* d_slab_in,

@@ -119,11 +119,13 @@ constexpr int kTileHeadStride = 16;      // uints between two XCDs' counters
 template <bool PERSIST>
 struct TileFeed {
     unsigned int* heads;
+    const unsigned int* order;       // (persistent) per-XCD lists of natural item ids, or nullptr: natural order
     unsigned int per_xcd, home, visit;
+    unsigned int item;               // x * per_xcd + natural id of the item handed out last (index of its cost record)
     int wave, lane;
     bool direct_done;
-    __device__ __forceinline__ TileFeed(unsigned int* h, unsigned int virtual_blocks, int w, int l)
-        : heads(h), per_xcd((virtual_blocks >> 3) * 4u), home(blockIdx.x & 7u), visit(0u), wave(w), lane(l), direct_done(false) {}
+    __device__ __forceinline__ TileFeed(unsigned int* h, unsigned int virtual_blocks, int w, int l, const unsigned int* ord = nullptr)
+        : heads(h), order(ord), per_xcd((virtual_blocks >> 3) * 4u), home(blockIdx.x & 7u), visit(0u), item(0u), wave(w), lane(l), direct_done(false) {}
     __device__ __forceinline__ bool next(unsigned int& vb, unsigned int& vq) {
         if (!PERSIST) {
             if (direct_done) return false;
@@ -136,7 +138,12 @@ struct TileFeed {
             unsigned int t = 0;
             if (lane == 0) t = atomicAdd(&heads[x * kTileHeadStride], 1u);
             t = (unsigned int)__builtin_amdgcn_readfirstlane((int)t);
-            if (t < per_xcd) { vb = (t >> 2) * 8u + x; vq = t & 3u; return true; }
+            if (t < per_xcd) {
+                if (order) t = order[x * per_xcd + t];                       // (wave-uniform address)
+                item = x * per_xcd + t;
+                vb = (t >> 2) * 8u + x; vq = t & 3u;
+                return true;
+            }
             ++visit;
         }
         return false;
@@ -988,7 +995,8 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
                                                     unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
                                                     uint32_t* __restrict__ samples, unsigned int* __restrict__ work_count,
                                                     unsigned int* __restrict__ work_list, unsigned long long* stats,
-                                                    unsigned int* __restrict__ tile_heads, unsigned int virtual_blocks) {
+                                                    unsigned int* __restrict__ tile_heads, unsigned int virtual_blocks,
+                                                    const unsigned int* __restrict__ tile_order, unsigned int* __restrict__ tile_cost) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int32_t* wnode = reinterpret_cast<int32_t*>(lds_pipe) + (size_t)wave * ((size_t)levels * 33);   // [levels] stacked node
@@ -996,12 +1004,13 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
     uint16_t* wbound = reinterpret_cast<uint16_t*>(wnode + levels) + lane;
     const unsigned int total = *hit_count;
     uint32_t nodes = 0, leaves = 0, slabs = 0, points = 0;        // wave-level (uniform)
+    uint32_t walk = 0;                                            // (persistent) node steps + triangle filters of the tile being walked
     // A work item is ONE WAVE's 64 queue entries (an 8x8-pixel tile of surface points) of virtual block vb = the block of the one-
     // workgroup-per-16x16-tile grid that k_primary filled them from.  tile_heads == nullptr: this workgroup IS virtual block
     // blockIdx.x (one item per wave).  Otherwise the grid is persistent and every WAVE pulls items from per-XCD counters (see
     // TileFeed): a wave that finishes a short walk starts the next tile at once instead of idling until the slowest of its
     // workgroup's four walks ends, and the launch ends when the longest single walk does, not the longest workgroup.
-    TileFeed<PERSIST> feed(tile_heads, virtual_blocks, wave, lane);
+    TileFeed<PERSIST> feed(tile_heads, virtual_blocks, wave, lane, tile_order);
     unsigned int vb, vq;
     while (feed.next(vb, vq)) {
     // Scene and frame are read from the kernel-argument segment WHERE an iteration needs them (kernarg_late): the per-tile prologue's
@@ -1023,6 +1032,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
     rec.sample = kInvalidHit;
     if (slot_i < total) rec = hits[slot_i];
     const bool valid = rec.sample != kInvalidHit;
+    if (PERSIST && tile_cost) { if (lane == 0) tile_cost[feed.item] = 0u; walk = 0u; }
     if (__ballot(valid) == 0ull) continue;                         // background tile
     const D3 lpos = mk(fc.light_pos_model[0], fc.light_pos_model[1], fc.light_pos_model[2]);
     const D3 E = valid ? mk(rec.pos[0], rec.pos[1], rec.pos[2]) + mk(rec.nrm[0], rec.nrm[1], rec.nrm[2]) * 0.001 : lpos * 0.5;   // ShadowMethod.cs:151
@@ -1061,6 +1071,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
         }
         const Bvh4Node n = load_uniform(&sc_arg.b4light[ni]);          // wave-uniform address: scalar loads
         nodes++;
+        if (PERSIST) walk += 2u;
         const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
         const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
         float a0, b0, a1, b1, a2, b2, a3, b3;                          // child u-intervals [a, b] of this lane's shaft
@@ -1078,6 +1089,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
             if (__ballot(hc && !done) == 0ull) return;
             leaves++;
             slabs += (uint32_t)cn;
+            if (PERSIST) walk += (uint32_t)cn;
             for (int q = 0; q < cn; ++q) {
                 const TriSlab s = load_uniform(&sc_arg.bslab[cc + q]); // scalar load
                 const bool live_q = hc && !done;
@@ -1136,8 +1148,40 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
         }
     }
     if (STATS) points += (uint32_t)__popcll(__ballot(valid));
+    if (PERSIST && tile_cost && lane == 0) tile_cost[feed.item] = walk;      // (the next frame walks the longest tiles first: k_tile_order)
     }   // while (feed.next)
     if (STATS) block_stat_add(&stats[6], &stats[7], &stats[10], &stats[11], nodes, leaves, slabs, points);
+}
+
+// k_tile_order -- one workgroup per XCD list: a STABLE two-way partition of the list's items (natural ids 0 .. per_xcd - 1) by the walk
+// length k_shaft_pkt4 measured for them: the long walks (>= quarters / 4 times the list's mean; 3 x by default) first, then the others, each part in natural
+// order -- neighbouring tiles share tree nodes and records in the XCD's L2, so the order inside a part is left alone.  A launch
+// ends when its last tile does: with the long walks handed out first, the tiles that remain at the end are short ones.
+__global__ __launch_bounds__(256) void k_tile_order(const unsigned int* __restrict__ cost, unsigned int* __restrict__ order, unsigned int per_xcd, unsigned int quarters) {
+    __shared__ unsigned long long ssum;
+    __shared__ unsigned int cnt[256];
+    const unsigned int x = blockIdx.x, tid = threadIdx.x;
+    const unsigned int* c = cost + (size_t)x * per_xcd;
+    unsigned int* o = order + (size_t)x * per_xcd;
+    if (tid == 0) ssum = 0ull;
+    __syncthreads();
+    const unsigned int chunk = (per_xcd + 255u) / 256u, i0 = min(per_xcd, tid * chunk), i1 = min(per_xcd, i0 + chunk);
+    unsigned long long sum = 0ull;
+    for (unsigned int i = i0; i < i1; ++i) sum += c[i];
+    atomicAdd(&ssum, sum);
+    __syncthreads();
+    const unsigned int thr = (unsigned int)min(0xffffffffull, (unsigned long long)quarters * ssum / (4ull * (unsigned long long)max(1u, per_xcd))) + 1u;   // quarters / 4 x the mean
+    unsigned int mine = 0;
+    for (unsigned int i = i0; i < i1; ++i) mine += c[i] >= thr ? 1u : 0u;
+    cnt[tid] = mine;
+    __syncthreads();
+    if (tid == 0) { unsigned int a = 0; for (int t = 0; t < 256; ++t) { const unsigned int v = cnt[t]; cnt[t] = a; a += v; } ssum = a; }
+    __syncthreads();
+    const unsigned int nlong = (unsigned int)ssum;
+    unsigned int pl = cnt[tid], ps = nlong + (i0 - cnt[tid]);
+    for (unsigned int i = i0; i < i1; ++i) {
+        if (c[i] >= thr) o[pl++] = i; else o[ps++] = i;
+    }
 }
 
 // undecided / escaped sample masks of a hit that moves on to the next round
@@ -1886,14 +1930,14 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
 // Same arithmetic per (hit point, candidate, sample) as k_shadow_cls<.., TAIL = false>, same verdicts, same pixels; the later rounds
 // (long lists, few hit points) keep k_shadow_cls.  SR_DBG_KERNEL_SWITCH 91 runs the first round on k_shadow_cls (cross-check, A/B).
 // --------------------------------------------------------------------------------------------------
-constexpr int kGrpItems = 8;             // hit points prepared together (one lane each)
+constexpr int kGrpItems = 16;            // hit points prepared together (one lane each)
 constexpr int kGrpRecs = 64;             // candidate records staged per fill (one lane each) >= the longest first-round list
 // LDS of one wave in float4 units: records (+ one of slack: the pair loop requests the record after the one it works on) + record
 // indices + the item table (4 float4 per hit point)
 constexpr int kGrpWaveF4 = (kGrpRecs + 1) * 5 + kGrpRecs / 4 + kGrpItems * 4;
 
 template <bool EXTRA, bool STATS>
-__global__ __launch_bounds__(256) void k_shadow_cls_g(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
+__global__ __launch_bounds__(256, 5) void k_shadow_cls_g(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
                                                       const HitRec* __restrict__ hits, const unsigned int* __restrict__ hit_count,
                                                       unsigned int count_cap, const unsigned int* __restrict__ index_list, int cap,
                                                       const unsigned int* __restrict__ cand_count, const int32_t* __restrict__ cand,
@@ -3303,15 +3347,25 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                 if (tn2 > 0) blocks = (unsigned)(xcd_tile_grid(L.fc.width, trows) * tn2);      // the grid of k_primary (x sub-samples)
                 unsigned int* heads;
                 const unsigned vblocks = blocks;
-                blocks = tile_grid(L, vblocks, 6, L.counters + kHeadsShaft, &heads);          // ... or the resident grid pulling its tiles
+                blocks = tile_grid(L, vblocks, (L.fc.debug >= 830 && L.fc.debug <= 836) ? L.fc.debug - 830 : 6, L.counters + kHeadsShaft, &heads);          // ... or the resident grid pulling its tiles (hook 830 + n: n workgroups per CU)
+                // (persistent) longest walks first: the lists k_tile_order made from the previous frame's walk lengths, if that frame had this tile grid
+                const unsigned long long order_tag = ((unsigned long long)vblocks << 32) | ((unsigned long long)(unsigned)L.fc.width << 12) | (unsigned long long)(unsigned)tn2;
+                const bool keep_cost = heads && L.tile_cost && L.tile_order && L.tile_order_tag && L.fc.debug != 84;
+                const unsigned int* order = (keep_cost && *L.tile_order_tag == order_tag) ? L.tile_order : nullptr;
+                unsigned int* cost = keep_cost ? L.tile_cost : nullptr;
                 const auto go = [&](auto kern) {
-                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats, heads, vblocks);
+                    hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, L.stream, L.sc, L.fc, (const HitRec*)L.hits, count_ptr, cap, lv4, tn2, trows, L.round_cand_count[round], L.round_cand[round], samples, work0, L.round_list[0], L.stats, heads, vblocks, order, cost);
                 };
                 // 6 waves/SIMD (85 VGPRs): 5.16 ms on the headline frame; 7 waves (72 VGPRs, spills in the node step) 5.44; 5 waves 5.61
                 // ((near, far) planes in the light-ordered copy, as in the camera-ordered one, were measured: fewer instructions, more spills at
                 //  this kernel's register budget -- 5.17 -> 5.30 ms; 5.49 ms at 5 waves/SIMD)
                 if (heads) { if (L.stats) go(k_shaft_pkt4<true, 6, true>); else go(k_shaft_pkt4<false, 6, true>); }
                 else { if (L.stats) go(k_shaft_pkt4<true, 6, false>); else go(k_shaft_pkt4<false, 6, false>); }
+                if (keep_cost) {
+                    hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(256), 0, L.stream, (const unsigned int*)L.tile_cost, L.tile_order, (vblocks >> 3) * 4u,
+                                       (L.fc.debug >= 840 && L.fc.debug < 880) ? (unsigned)(L.fc.debug - 840) : 12u);   // long = >= 3 x the mean (2 x: 1.41 ms per rank of 8, 3 x: 1.37, 4 x: 1.40)
+                    *L.tile_order_tag = order_tag;
+                }
             } else if (first && !(L.per_lane_shaft & 1)) {
                 // round 1 on the binary tree (cross-check): one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
                 size_t lds = ((size_t)levels * 4 + (size_t)levels * 64 * 2) * 4;
@@ -3577,5 +3631,7 @@ int pipeline_round_cap_max(int round) { return round == 0 ? 64 : 1024; }
 int pipeline_bounce_lds_levels() { return kBounceLdsLevels; }
 size_t pipeline_round_state_bytes() { return sizeof(RoundState); }
 size_t pipeline_counter_bytes() { return (size_t)kCounterWords * sizeof(unsigned int); }
+// 8x8-pixel tiles (one wave's work items) of the padded super-tile grid of a band, all sub-samples
+size_t pipeline_tile_items(int width, int rows, int n2) { return (size_t)xcd_tile_grid(width, rows) * (size_t)n2 * 4; }
 
 }  // namespace sr
