@@ -108,8 +108,12 @@ def main():
         "frame": dict(cfg["frame"], max_bounces=cfg["bounce"][0], reflectivity=cfg["bounce"][1], pose="RendererTests yaw 135 pitch -22", shading=True,
                       shadow_samples=100 if cfg["frame"].get("shadows") else 0, tree="reference 15/25"),
         "oracle_commit": commit,
-        "command": "python scripts/make_frame_fixtures.py " + " ".join(sys.argv[1:]),
+        "command": "python scripts/make_frame_fixtures.py " + a.config + "   (strips may be made in several runs: see invocations)",
     })
+    inv = "python scripts/make_frame_fixtures.py " + " ".join(sys.argv[1:])
+    doc.setdefault("invocations", [])
+    if inv not in doc["invocations"]:
+        doc["invocations"].append(inv)
     want = [s for s in parse_strips(a.strips, total) if str(s) not in doc["strips"]]
     print("%s: %d strips to render (%d already in %s)" % (a.config, len(want), len(doc["strips"]), os.path.relpath(path, ROOT)), flush=True)
     if not want:

@@ -60,7 +60,7 @@ def test_fixture_files_are_well_formed():
         assert doc["config"] == n and doc["oracle_commit"] and doc["command"].startswith("python scripts/make_frame_fixtures.py")
         assert 0 < len(doc["strips"]) <= doc["strips_total"] == doc["height"] // STRIP
         assert all(0 <= int(k) < doc["strips_total"] and 0 <= v <= 0xFFFFFFFF for k, v in doc["strips"].items())
-    for n in ("c2", "c2_shadows"):
+    for n in ("c2", "c2_shadows", "c3"):
         if n in names:
             doc = json.load(open(os.path.join(FRAMES, n + ".json")))
             assert len(doc["strips"]) == doc["strips_total"], n
