@@ -56,9 +56,9 @@ def profile_dir(args):
     """committed rocprofv3 summaries of this workload (the newest round that has them)"""
     if args.tris == 10000000:
         which = "bounces" if args.bounces > 0 else "shadows"
-        cands = [os.path.join("r03_c5", "final_" + which), os.path.join("r03_c5", which)]
+        cands = [os.path.join("r04_c5", which), os.path.join("r03_c5", "final_" + which), os.path.join("r03_c5", which)]
     else:
-        cands = ["r03_final", "r02_final"]
+        cands = ["r04_final", "r03_final", "r02_final"]
     for c in cands:
         d = os.path.join(ROOT, "profiles", c)
         if os.path.exists(os.path.join(d, "sq_counters_summary.csv")):

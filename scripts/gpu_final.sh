@@ -1,7 +1,7 @@
 # End-of-round evidence in one GPU call: smoke, rocprofv3 passes of the headline workload, default bench (with the fresh SQ summary), strip replay,
 # the other BASELINE configs through the Renderer mirror, both multi-GPU rehearsals, C5 benches.
 # usage (GPU box): bash scripts/gpu_final.sh <tag> <profiles dir>      e.g. bash scripts/gpu_final.sh r03 profiles/r03_final
-TAG=${1:-r03}; DIR=${2:-profiles/r03_final}
+TAG=${1:-r04}; DIR=${2:-profiles/r04_final}
 mkdir -p gpurun_out $DIR
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/smoke.log 2>&1 || exit 1
 bash scripts/gpu_profile.sh $TAG > gpurun_out/prof_$TAG.log 2>&1 || exit 1
