@@ -1159,28 +1159,46 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
 // ends when its last tile does: with the long walks handed out first, the tiles that remain at the end are short ones.
 __global__ __launch_bounds__(256) void k_tile_order(const unsigned int* __restrict__ cost, unsigned int* __restrict__ order, unsigned int per_xcd, unsigned int quarters) {
     __shared__ unsigned long long ssum;
-    __shared__ unsigned int cnt[256];
-    const unsigned int x = blockIdx.x, tid = threadIdx.x;
+    __shared__ unsigned int wcnt[4];
+    const unsigned int x = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const unsigned int* c = cost + (size_t)x * per_xcd;
     unsigned int* o = order + (size_t)x * per_xcd;
     if (tid == 0) ssum = 0ull;
     __syncthreads();
-    const unsigned int chunk = (per_xcd + 255u) / 256u, i0 = min(per_xcd, tid * chunk), i1 = min(per_xcd, i0 + chunk);
     unsigned long long sum = 0ull;
-    for (unsigned int i = i0; i < i1; ++i) sum += c[i];
-    atomicAdd(&ssum, sum);
+    for (unsigned int i = tid; i < per_xcd; i += 256u) sum += c[i];
+    for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
+    if (lane == 0) atomicAdd(&ssum, sum);
     __syncthreads();
     const unsigned int thr = (unsigned int)min(0xffffffffull, (unsigned long long)quarters * ssum / (4ull * (unsigned long long)max(1u, per_xcd))) + 1u;   // quarters / 4 x the mean
-    unsigned int mine = 0;
-    for (unsigned int i = i0; i < i1; ++i) mine += c[i] >= thr ? 1u : 0u;
-    cnt[tid] = mine;
+    // wave w owns a contiguous segment of the list (coalesced batches of 64 items): count its long walks, then place both kinds
+    const unsigned int seg = ((per_xcd + 3u) / 4u + 63u) / 64u * 64u, i0 = min(per_xcd, w * seg), i1 = min(per_xcd, i0 + seg);
+    unsigned int cnt = 0;
+    for (unsigned int b = i0; b < i1; b += 256u) {                       // (four batches of 64 in flight: the loop is load latency)
+        unsigned int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const unsigned int i = b + 64u * u + lane; v[u] = i < i1 ? c[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt += (unsigned int)__popcll(__ballot(v[u] >= thr));
+    }
+    if (lane == 0) wcnt[w] = cnt;
     __syncthreads();
-    if (tid == 0) { unsigned int a = 0; for (int t = 0; t < 256; ++t) { const unsigned int v = cnt[t]; cnt[t] = a; a += v; } ssum = a; }
-    __syncthreads();
-    const unsigned int nlong = (unsigned int)ssum;
-    unsigned int pl = cnt[tid], ps = nlong + (i0 - cnt[tid]);
-    for (unsigned int i = i0; i < i1; ++i) {
-        if (c[i] >= thr) o[pl++] = i; else o[ps++] = i;
+    unsigned int before = 0, nlong = 0;
+    for (unsigned int k = 0; k < 4u; ++k) { const unsigned int v = wcnt[k]; if (k < w) before += v; nlong += v; }
+    unsigned int pl = before, ps = nlong + (i0 - before);
+    for (unsigned int b = i0; b < i1; b += 256u) {
+        unsigned int v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const unsigned int i = b + 64u * u + lane; v[u] = i < i1 ? c[i] : 0u; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned int i = b + 64u * u + lane;
+            const bool in = i < i1, lg = in && v[u] >= thr;
+            const unsigned long long ml = __ballot(lg), ms = __ballot(in && !lg), lt = lanemask_lt();
+            if (lg) o[pl + (unsigned int)__popcll(ml & lt)] = i;
+            else if (in) o[ps + (unsigned int)__popcll(ms & lt)] = i;
+            pl += (unsigned int)__popcll(ml); ps += (unsigned int)__popcll(ms);
+        }
     }
 }
 
@@ -2732,6 +2750,7 @@ struct alignas(16) BounceHit {
     int32_t bestK, pad;          // its record (-1: none)
 };
 static_assert(sizeof(BounceHit) == 16, "BounceHit must be 16 bytes");
+constexpr int kWalkNodeBurst = -1, kWalkLeafBurst = -1;   // node steps / leaves per phase of k_bounce_walk (-1: unlimited); SR_DBG_KERNEL_SWITCH 300 + 10 B + L
 constexpr int kWalkRefillAt = 24;        // k_bounce_walk fetches new rays when at most this many lanes are still walking (8: 43.4 ms, 24: 43.3, 32: 43.9, 48: 45.3, 62: 47.5 at C5)
 // The worst case of a lane's stack is 3 * depth + 2 entries -- 60 KB of LDS per workgroup at C5, i.e. two workgroups per CU, and an
 // incoherent walk lives on the number of waves that wait side by side.  Only the first kBounceLdsLevels live in LDS; the deeper
@@ -2774,7 +2793,7 @@ __global__ __launch_bounds__(256) void k_bounce_prep(DevScene sc, const HitRec* 
 template <bool STATS, bool WIDE>
 __global__ __launch_bounds__(256) void k_bounce_walk(DevScene sc, const BounceRay* __restrict__ prep, const unsigned int* __restrict__ count,
                                                      unsigned int* __restrict__ head, BounceHit* __restrict__ res, unsigned long long* stats, int refill_at,
-                                                     int32_t* __restrict__ deep, int lds_levels) {
+                                                     int32_t* __restrict__ deep, int lds_levels, int node_burst, int leaf_burst) {
     const int tid = threadIdx.x, lane = tid & 63;
     SplitStack st{reinterpret_cast<int32_t*>(lds_pipe) + tid, deep + (size_t)blockIdx.x * 256u + (unsigned)tid, lds_levels, (int32_t)(gridDim.x * 256u)};
     const unsigned int total = *count;
@@ -2829,7 +2848,8 @@ __global__ __launch_bounds__(256) void k_bounce_walk(DevScene sc, const BounceRa
         }
         if (active) {
             // (the speculative walk of k_bounce: up to eight pending leaves, on while at most four wait)
-            while (WIDE && ni >= 0 && leafE < 0) {
+            int nb = node_burst;                                   // (node steps / leaves per phase: the lanes of a wave advance in small, equal increments)
+            while (WIDE && ni >= 0 && leafE < 0 && nb-- != 0) {
                 const Bvh4Node n = sc.b4[ni];
                 sec.nodes++;
                 float tk[4];
@@ -2878,7 +2898,8 @@ __global__ __launch_bounds__(256) void k_bounce_walk(DevScene sc, const BounceRa
                 else if (i1) ni = n.c1;
                 else ni = (sp > 0) ? st.get(--sp) : -1;
             }
-            while (leafA >= 0) {
+            int lb = leaf_burst;
+            while (leafA >= 0 && lb-- != 0) {
                 const int32_t first = leafA & kLeafMask, cn = (leafA >> kLeafShift) & 15;
                 leafA = leafB;
                 leafB = WIDE ? leafC : -1;
@@ -3325,6 +3346,8 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
     // counters: [0] hits  [1] k_shadow head  [2..] items entering round 1, 2, ..  [2+R-1] fallback count  [6] round-0 work items
     unsigned int* fb_count = L.counters + 2 + (kShaftRounds - 1);
     unsigned int* work0 = L.counters + 6;
+    unsigned int order_items = 0;                 // > 0: the persistent shaft walk left its tiles' walk lengths behind (see below)
+    unsigned long long order_new_tag = 0;
     for (int round = 0; round < kShaftRounds; ++round) {
         const bool first = round == 0, last = round == kShaftRounds - 1;
         const unsigned int* count_ptr = first ? L.counters : L.counters + 1 + round;
@@ -3361,11 +3384,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                 //  this kernel's register budget -- 5.17 -> 5.30 ms; 5.49 ms at 5 waves/SIMD)
                 if (heads) { if (L.stats) go(k_shaft_pkt4<true, 6, true>); else go(k_shaft_pkt4<false, 6, true>); }
                 else { if (L.stats) go(k_shaft_pkt4<true, 6, false>); else go(k_shaft_pkt4<false, 6, false>); }
-                if (keep_cost) {
-                    hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(256), 0, L.stream, (const unsigned int*)L.tile_cost, L.tile_order, (vblocks >> 3) * 4u,
-                                       (L.fc.debug >= 840 && L.fc.debug < 880) ? (unsigned)(L.fc.debug - 840) : 12u);   // long = >= 3 x the mean (2 x: 1.41 ms per rank of 8, 3 x: 1.37, 4 x: 1.40)
-                    *L.tile_order_tag = order_tag;
-                }
+                if (keep_cost) { order_items = (vblocks >> 3) * 4u; order_new_tag = order_tag; }
             } else if (first && !(L.per_lane_shaft & 1)) {
                 // round 1 on the binary tree (cross-check): one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)
                 size_t lds = ((size_t)levels * 4 + (size_t)levels * 64 * 2) * 4;
@@ -3455,6 +3474,13 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
         if ((e = hipGetLastError()) != hipSuccess) return e;
     }
     if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
+    // the next frame's longest-first tile lists, from this frame's walk lengths: last in the stage (nothing of this frame waits for it)
+    if (order_items) {
+        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(256), 0, L.stream, (const unsigned int*)L.tile_cost, L.tile_order, order_items,
+                           (L.fc.debug >= 840 && L.fc.debug < 880) ? (unsigned)(L.fc.debug - 840) : 12u);   // long = >= 3 x the mean (2 x: 1.41 ms per rank of 8, 3 x: 1.37, 4 x: 1.40)
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        *L.tile_order_tag = order_new_tag;
+    }
     return hipSuccess;
 }
 
@@ -3525,7 +3551,9 @@ static hipError_t launch_pipeline_t(const PipelineLaunch& L) {
                     if ((size_t)(levels_all - lds_levels) * (size_t)blocks * 256 * 4 > L.bounce_stack_bytes || !L.bounce_stack) lds_levels = levels_all;
                     const auto walk = [&](auto kern) {
                         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), (size_t)lds_levels * 256 * 4, L.stream, L.sc, (const BounceRay*)prep, L.counters + cur, L.counters + 2, res, L.stats,
-                                           (L.fc.debug >= 100 && L.fc.debug < 164) ? L.fc.debug - 100 : kWalkRefillAt, L.bounce_stack, lds_levels);
+                                           (L.fc.debug >= 100 && L.fc.debug < 164) ? L.fc.debug - 100 : kWalkRefillAt, L.bounce_stack, lds_levels,
+                                           (L.fc.debug >= 300 && L.fc.debug < 400) ? ((L.fc.debug - 300) / 10 ? (L.fc.debug - 300) / 10 : -1) : kWalkNodeBurst,
+                                           (L.fc.debug >= 300 && L.fc.debug < 400) ? ((L.fc.debug - 300) % 10 ? (L.fc.debug - 300) % 10 : -1) : kWalkLeafBurst);
                     };
                     if (wide) { if (L.stats) walk(k_bounce_walk<true, true>); else walk(k_bounce_walk<false, true>); }
                     else { if (L.stats) walk(k_bounce_walk<true, false>); else walk(k_bounce_walk<false, false>); }
