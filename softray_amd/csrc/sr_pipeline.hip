@@ -1005,6 +1005,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
     const unsigned int total = *hit_count;
     uint32_t nodes = 0, leaves = 0, slabs = 0, points = 0;        // wave-level (uniform)
     uint32_t walk = 0;                                            // (persistent) node steps + triangle filters of the tile being walked
+    uint32_t top21 = 0, top85 = 0;                                // (STATS) node steps in the top three / four levels of the tree (level order: node < 21 / < 85)
     // A work item is ONE WAVE's 64 queue entries (an 8x8-pixel tile of surface points) of virtual block vb = the block of the one-
     // workgroup-per-16x16-tile grid that k_primary filled them from.  tile_heads == nullptr: this workgroup IS virtual block
     // blockIdx.x (one item per wave).  Otherwise the grid is persistent and every WAVE pulls items from per-XCD counters (see
@@ -1071,6 +1072,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
         }
         const Bvh4Node n = load_uniform(&sc_arg.b4light[ni]);          // wave-uniform address: scalar loads
         nodes++;
+        if (STATS) { top21 += ni < 21 ? 1u : 0u; top85 += ni < 85 ? 1u : 0u; }
         if (PERSIST) walk += 2u;
         const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
         const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
@@ -1151,6 +1153,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
     if (PERSIST && tile_cost && lane == 0) tile_cost[feed.item] = walk;      // (the next frame walks the longest tiles first: k_tile_order)
     }   // while (feed.next)
     if (STATS) block_stat_add(&stats[6], &stats[7], &stats[10], &stats[11], nodes, leaves, slabs, points);
+    if (STATS && lane == 0) { atomicAdd(work_count - 2, top21); atomicAdd(work_count - 1, top85); }      // diagnostics: sr_debug_counters [4], [5] (free on the shaft path)
 }
 
 // k_tile_order -- one workgroup per XCD list: a STABLE two-way partition of the list's items (natural ids 0 .. per_xcd - 1) by the walk
