@@ -1953,9 +1953,13 @@ __global__ __launch_bounds__(256) void k_shadow_cls(DevScene sc, FrameConst fc, 
 // --------------------------------------------------------------------------------------------------
 constexpr int kGrpItems = 16;            // hit points prepared together (one lane each)
 constexpr int kGrpRecs = 64;             // candidate records staged per fill (one lane each) >= the longest first-round list
+constexpr int kGrpQueue = 64;            // undecided (hit point, sample, record) pairs a wave collects before it runs the FP64 tests for all of them
 // LDS of one wave in float4 units: records (+ one of slack: the pair loop requests the record after the one it works on) + record
-// indices + the item table (4 float4 per hit point)
-constexpr int kGrpWaveF4 = (kGrpRecs + 1) * 5 + kGrpRecs / 4 + kGrpItems * 4;
+// indices + the item table (7 float4 per hit point: [0..1] fp32 frame + shaded colour, [2] ids, [3] alive / [4] escaped sample masks
+// (4 words = 128 samples each), [5] blocked / [6] dead verdicts of the FP64 tests) + the queue of undecided pairs (2 words each): 7.6 KB,
+// five workgroups per CU
+constexpr int kGrpItemF4 = 7;
+constexpr int kGrpWaveF4 = (kGrpRecs + 1) * 5 + kGrpRecs / 4 + kGrpItems * kGrpItemF4 + kGrpQueue / 2;
 
 template <bool EXTRA, bool STATS>
 __global__ __launch_bounds__(256, 5) void k_shadow_cls_g(DevScene sc, FrameConst fc, const double* __restrict__ offsets,
@@ -1972,7 +1976,9 @@ __global__ __launch_bounds__(256, 5) void k_shadow_cls_g(DevScene sc, FrameConst
     typedef float f4 __attribute__((ext_vector_type(4)));
     float4* wc = reinterpret_cast<float4*>(lds_pipe) + (size_t)wave * kGrpWaveF4;        // [kGrpRecs + 1][5] cone-plane records
     int32_t* wrecidx = reinterpret_cast<int32_t*>(wc + (kGrpRecs + 1) * 5);             // [kGrpRecs] record position of every staged candidate
-    float4* witem = reinterpret_cast<float4*>(wrecidx + kGrpRecs);                      // [kGrpItems][4] per-hit-point constants
+    float4* witem = reinterpret_cast<float4*>(wrecidx + kGrpRecs);                      // [kGrpItems][kGrpItemF4] per-hit-point constants, masks, verdicts
+    uint32_t* wmask = reinterpret_cast<uint32_t*>(witem);                               // (the same table as words: item j at wmask + j * kGrpItemF4 * 4)
+    uint2* wqueue = reinterpret_cast<uint2*>(witem + kGrpItems * kGrpItemF4);           // [kGrpQueue] (item | sample << 8, record position)
     const int S = fc.shadow_samples;
     uint32_t* light_byte = reinterpret_cast<uint32_t*>(reinterpret_cast<float4*>(lds_pipe) + 4 * kGrpWaveF4);   // (see k_shadow_cls)
     for (int e = tid; e <= S; e += 256) {
@@ -1996,6 +2002,36 @@ __global__ __launch_bounds__(256, 5) void k_shadow_cls_g(DevScene sc, FrameConst
         OZ = (f2){(float)offsets[3 * j0 + 2], (float)offsets[3 * j1 + 2]};
     }
     uint32_t n_rays = 0, n_items = 0, n_recs = 0, n_cls = 0, n_exact = 0;
+    int qn = 0;                                                          // (wave-uniform) undecided pairs waiting in wqueue
+    // The reference's FP64 arithmetic for the pairs the fp32 bounds could not decide (0.1 % of them), one pair per lane, for a whole
+    // group of hit points at once: inline it ran with one or two lanes active for ~400 instructions whenever a hit point had such a
+    // pair -- a sixth of the kernel for a thousandth of the pairs.  A blocked sample loses its bit in the hit point's "escaped" mask, a
+    // sample whose ray misses the root box is decided (nothing can block it): verdict words of the item table, ORed in.
+    const auto flush_queue = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int qb = 0; qb < qn; qb += 64) {
+            const int p = qb + lane;
+            if (p < qn) {
+                const uint2 e = wqueue[p];
+                const unsigned int ij = e.x & 0xffu, sj = e.x >> 8;
+                const unsigned int hq = wmask[ij * (kGrpItemF4 * 4) + 8];                       // item table word [2].x: the hit index
+                const HitRec rq = hits[hq];
+                const D3 E = mk(rq.pos[0], rq.pos[1], rq.pos[2]) + mk(rq.nrm[0], rq.nrm[1], rq.nrm[2]) * 0.001;
+                const D3 rs = lpos + mk(offsets[3 * sj], offsets[3 * sj + 1], offsets[3 * sj + 2]);
+                SampleRay ray;
+                const RootBox root = kernarg_late<RootBox>(offsetof(DevScene, root));   // (the scene is the kernel's first argument)
+                const bool in_box = prepare_sample(root, rs, E - rs, ray);              // false: the ray misses the root box, nothing can block it
+                if (STATS) n_exact++;
+                uint32_t* verdict = wmask + ij * (kGrpItemF4 * 4) + 20;                  // [5] blocked: words 0..3 (sample s: word s / 32), [6] dead: words 4..7
+                if (!in_box) atomicOr(&verdict[4 + (sj >> 5)], 1u << (sj & 31u));
+                else if (tri_blocks(sc.btris[e.y].p, ray, root.lo, root.hi)) atomicOr(&verdict[sj >> 5], 1u << (sj & 31u));
+            }
+        }
+        qn = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
     const unsigned int nwaves = gridDim.x * 4u;
     const unsigned int s0 = blockIdx.x * 4u + (unsigned)wave;
     for (unsigned int slot_g = s0; slot_g < total; slot_g += nwaves * (unsigned)kGrpItems) {
@@ -2014,10 +2050,11 @@ __global__ __launch_bounds__(256, 5) void k_shadow_cls_g(DevScene sc, FrameConst
             const float dmax = __builtin_amdgcn_sqrtf(dlx * dlx + dly * dly + dlz * dlz) * 1.0001f + cf.R;   // an upper bound is all it has to be
             const uint32_t shaded = (fc.flags & 32u) ? 0u : samples[rec.sample];
             my_ntri = (int)(cc & 0xffffu);
-            witem[lane * 4 + 0] = make_float4(efx, efy, efz, dlx);
-            witem[lane * 4 + 1] = make_float4(dly, dlz, dmax, 0.0f);
-            witem[lane * 4 + 2] = make_float4(__uint_as_float(h), __uint_as_float(rec.sample), __uint_as_float(rec.pad[0]), __uint_as_float(cc));
-            witem[lane * 4 + 3] = make_float4(__uint_as_float(shaded), 0.0f, 0.0f, 0.0f);
+            witem[lane * kGrpItemF4 + 0] = make_float4(efx, efy, efz, dlx);
+            witem[lane * kGrpItemF4 + 1] = make_float4(dly, dlz, dmax, __uint_as_float(shaded));
+            witem[lane * kGrpItemF4 + 2] = make_float4(__uint_as_float(h), __uint_as_float(rec.sample), __uint_as_float(rec.pad[0]), __uint_as_float(cc));
+            witem[lane * kGrpItemF4 + 5] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // FP64 verdicts (flush_queue ORs into them): blocked samples,
+            witem[lane * kGrpItemF4 + 6] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // samples whose ray misses the root box
         }
         int incl = my_ntri;                                               // inclusive prefix sum of the list lengths over the group's lanes
 #pragma unroll
@@ -2044,7 +2081,7 @@ __global__ __launch_bounds__(256, 5) void k_shadow_cls_g(DevScene sc, FrameConst
                     const int o = __builtin_amdgcn_readlane(excl, j) - base;
                     if (lane >= o) { jj = j; ofs = o; }
                 }
-                const float4 i0 = witem[jj * 4 + 0], i1 = witem[jj * 4 + 1], i2 = witem[jj * 4 + 2];
+                const float4 i0 = witem[jj * kGrpItemF4 + 0], i1 = witem[jj * kGrpItemF4 + 1], i2 = witem[jj * kGrpItemF4 + 2];
                 const float efx = i0.x, efy = i0.y, efz = i0.z, dlx = i0.w, dly = i1.x, dlz = i1.y, dmax = i1.z;
                 const unsigned int hj = __float_as_uint(i2.x);
                 const int32_t ent = cand[(size_t)hj * cap + (lane - ofs)];
@@ -2082,11 +2119,10 @@ __global__ __launch_bounds__(256, 5) void k_shadow_cls_g(DevScene sc, FrameConst
             // ---- the hit points of this fill, one after the other: lanes = samples ----
             for (int j = ja; j < jb; ++j) {
                 const int off_local = __builtin_amdgcn_readlane(excl, j) - base;
-                const float4 i0 = witem[j * 4 + 0], i1 = witem[j * 4 + 1], i2 = witem[j * 4 + 2], i3 = witem[j * 4 + 3];
+                const float4 i0 = witem[j * kGrpItemF4 + 0], i1 = witem[j * kGrpItemF4 + 1], i2 = witem[j * kGrpItemF4 + 2];
                 const auto uni = [](float v) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v))); };
                 const float efx = uni(i0.x), efy = uni(i0.y), efz = uni(i0.z), dlx = uni(i0.w), dly = uni(i1.x), dlz = uni(i1.y), dmax = uni(i1.z);
-                const unsigned int h = __float_as_uint(uni(i2.x)), rec_sample = __float_as_uint(uni(i2.y)), rec_cell = __float_as_uint(uni(i2.z)), cc = __float_as_uint(uni(i2.w));
-                const uint32_t shaded = __float_as_uint(uni(i3.x));
+                const unsigned int h = __float_as_uint(uni(i2.x)), cc = __float_as_uint(uni(i2.w));
                 n_items++;
                 const int ntri = (int)(cc & 0xffffu);
                 const bool truncated = (cc & kTruncated) != 0;
@@ -2166,63 +2202,77 @@ __global__ __launch_bounds__(256, 5) void k_shadow_cls_g(DevScene sc, FrameConst
                     if (k > 0) { unc[0] = __brev(unc[0]) >> (32 - k); unc[1] = __brev(unc[1]) >> (32 - k); }   // bit j = candidate j
                     if (((blk0 >> lane) & 1ull) != 0ull && alive[0]) { alive[0] = false; escaped[0] = false; }
                     if (((blk1 >> lane) & 1ull) != 0ull && alive[1]) { alive[1] = false; escaped[1] = false; }
-                    // ---- the undecided pairs of the samples no candidate blocked so far: the reference's FP64 arithmetic (rare) ----
-                    if (__any((alive[0] && unc[0] != 0u) || (alive[1] && unc[1] != 0u))) {
-                        const HitRec rq = hits[h];
-                        const D3 E = mk(rq.pos[0], rq.pos[1], rq.pos[2]) + mk(rq.nrm[0], rq.nrm[1], rq.nrm[2]) * 0.001;
+                    // ---- the undecided pairs of the samples no candidate blocked so far go to the wave's queue (FP64 tests for a whole
+                    //      group at once: flush_queue); such a sample stays alive for the candidates that follow (one of them may block it) ----
+                    if (fc.debug != 92 && __any((alive[0] && unc[0] != 0u) || (alive[1] && unc[1] != 0u))) {      // (hook 92: TIMING EXPERIMENT ONLY, wrong pixels)
 #pragma unroll 1
                         for (int q = 0; q < kPacketSlots; ++q) {
                             uint32_t m = (q ? alive[1] : alive[0]) ? (q ? unc[1] : unc[0]) : 0u;
-                            if (m) {
-                                const int sj = lane + 64 * q;
-                                const D3 rs = lpos + mk(offsets[3 * sj], offsets[3 * sj + 1], offsets[3 * sj + 2]);
-                                SampleRay ray;
-                                const RootBox root = kernarg_late<RootBox>(offsetof(DevScene, root));   // (the scene is the kernel's first argument)
-                                bool is_alive = prepare_sample(root, rs, E - rs, ray);  // false: the ray misses the root box, nothing can block it
-                                bool blocked = false;
-                                while (is_alive && m) {
+                            while (__any(m != 0u)) {
+                                const bool has = m != 0u;
+                                const unsigned long long b = __ballot(has);
+                                const int np = (int)__popcll(b);
+                                if (qn + np > kGrpQueue) flush_queue();                   // (wave-uniform; the verdicts are ORed into the item table)
+                                if (has) {
                                     const int kk = __ffs((int)m) - 1;
                                     m &= m - 1u;
-                                    if (STATS) n_exact++;
-                                    if (tri_blocks(sc.btris[wrecidx[off_local + cbase + kk]].p, ray, root.lo, root.hi)) { is_alive = false; blocked = true; }
+                                    wqueue[qn + (int)__popcll(b & lanemask_lt())] = make_uint2((unsigned int)j | ((unsigned int)(lane + 64 * q) << 8),
+                                                                                               (unsigned int)wrecidx[off_local + cbase + kk]);
                                 }
-                                if (!is_alive) {
-                                    if (q) { alive[1] = false; if (blocked) escaped[1] = false; }
-                                    else { alive[0] = false; if (blocked) escaped[0] = false; }
-                                }
+                                qn += np;
                             }
                         }
                     }
                     have = __any(alive[0] || alive[1]);
                 }
-                if (have && truncated) {
-                    // the list ran out before the shaft did and some sample is still undecided: next round, or the exact fallback
+                // ---- the hit point's sample masks wait in the item table for the FP64 verdicts (group epilogue below) ----
+                {
                     const unsigned long long a0m = __ballot(alive[0]), a1m = __ballot(alive[1]), e0 = __ballot(escaped[0]), e1m = __ballot(escaped[1]);
                     if (lane == 0) {
-                        unsigned int slot = next_count ? atomicAdd(next_count, 1u) : 0xffffffffu;
-                        RoundState o;
-                        o.alive[0] = a0m; o.alive[1] = a1m; o.escaped[0] = e0; o.escaped[1] = e1m;
-                        if (slot < next_cap) {
-                            next_list[slot] = h;
-                            state_out[slot] = o;
-                        } else {
-                            const unsigned int fi = atomicAdd(last_count, 1u);    // the fallback only traces the undecided samples
-                            last_list[fi] = h;
-                            last_state[fi] = o;
-                        }
-                    }
-                } else {
-                    const int esc = (int)__popcll(__ballot(escaped[0])) + (int)__popcll(__ballot(escaped[1]));
-                    if (lane == 0) {                                               // finish_hit with the tabulated byte
-                        if (fc.flags & 32u) sc.shadow_cache[rec_cell] = (uint8_t)light_byte[esc];
-                        else if (fc.accum) fc.accum[rec_sample] += (uint32_t)esc;      // (one chunk of a > 128-sample frame)
-                        else samples[rec_sample] = modulate(shaded, light_byte[esc]);
+                        uint32_t* w = wmask + j * (kGrpItemF4 * 4) + 12;
+                        w[0] = (uint32_t)a0m; w[1] = (uint32_t)(a0m >> 32); w[2] = (uint32_t)a1m; w[3] = (uint32_t)(a1m >> 32);
+                        w[4] = (uint32_t)e0; w[5] = (uint32_t)(e0 >> 32); w[6] = (uint32_t)e1m; w[7] = (uint32_t)(e1m >> 32);
                     }
                 }
             }
             ja = jb;
             __builtin_amdgcn_wave_barrier();                              // (the next fill overwrites the records)
         }
+        // ---- group epilogue, lane = hit point: FP64 verdicts in, pixel (or next round) out ----
+        flush_queue();
+        if (lane < nitems) {
+            const uint32_t* w = wmask + lane * (kGrpItemF4 * 4);
+            const unsigned int h = w[8], rec_sample = w[9], rec_cell = w[10], cc = w[11];
+            const uint32_t shaded = w[7];
+            unsigned long long al[2], es[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned long long blocked = (unsigned long long)w[20 + 2 * q] | ((unsigned long long)w[21 + 2 * q] << 32);
+                const unsigned long long dead = (unsigned long long)w[24 + 2 * q] | ((unsigned long long)w[25 + 2 * q] << 32);
+                al[q] = ((unsigned long long)w[12 + 2 * q] | ((unsigned long long)w[13 + 2 * q] << 32)) & ~blocked & ~dead;
+                es[q] = ((unsigned long long)w[16 + 2 * q] | ((unsigned long long)w[17 + 2 * q] << 32)) & ~blocked;
+            }
+            if ((al[0] | al[1]) != 0ull && (cc & kTruncated) != 0u) {
+                // the list ran out before the shaft did and some sample is still undecided: next round, or the exact fallback
+                unsigned int slot = next_count ? atomicAdd(next_count, 1u) : 0xffffffffu;
+                RoundState o;
+                o.alive[0] = al[0]; o.alive[1] = al[1]; o.escaped[0] = es[0]; o.escaped[1] = es[1];
+                if (slot < next_cap) {
+                    next_list[slot] = h;
+                    state_out[slot] = o;
+                } else {
+                    const unsigned int fi = atomicAdd(last_count, 1u);    // the fallback only traces the undecided samples
+                    last_list[fi] = h;
+                    last_state[fi] = o;
+                }
+            } else {
+                const int esc = (int)__popcll(es[0]) + (int)__popcll(es[1]);      // finish_hit with the tabulated byte
+                if (fc.flags & 32u) sc.shadow_cache[rec_cell] = (uint8_t)light_byte[esc];
+                else if (fc.accum) fc.accum[rec_sample] += (uint32_t)esc;      // (one chunk of a > 128-sample frame)
+                else samples[rec_sample] = modulate(shaded, light_byte[esc]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                                  // (the next group's stage 0 overwrites the item table)
     }
     if (STATS) {
         uint32_t a = wave_sum(n_rays), b = wave_sum(n_cls), c = wave_sum(n_exact);
