@@ -745,6 +745,9 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         P.band_rows = (int32_t)band_rows;
         P.row_first = h * rows_half;
         P.row_limit = std::min(fc.num_rows, (h + 1) * rows_half);
+        // workgroups per CU of the persistent shaft walk: two pipelines side by side leave each other room (a rank of an 8-way split: 1.41 -> 1.32 ms,
+        // whole frame unchanged); a pipeline that has the chip to itself fills it (3.9 against 5.5 ms for the walk alone)
+        P.shaft_wgs_per_cu = (split && !sequential_parts) ? 3 : 6;
         P.persistent_blocks = s->num_cus * 8;
         P.per_lane_shadows = (f->flags & SR_F_PER_LANE_SHADOWS) != 0;
         P.exact_shadow_tests = s->dbg[SR_DBG_EXACT_SHADOW_TESTS] > 0;

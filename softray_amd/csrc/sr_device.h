@@ -102,6 +102,7 @@ struct PipelineLaunch {
     bool        per_lane_primary; // k_primary with private walks instead of the packet walk + camera-cone filter (cross-check)
     bool        bvh2_packets;     // the packet walks on the two-wide tree with a per-step vote (round 2's kernels; cross-check)
     bool        primary_stats_only;   // `stats` counts the primary rays only (SR_F_PRIMARY_STATS_ONLY): the shadow / bounce stages run their uncounted instantiations
+    int32_t     shaft_wgs_per_cu; // resident workgroups per CU of the persistent shaft walk (0 = 6)
     bool        shadows_on_bvh;   // mode != BVH: the shadow rays of a dynamic frame are traced on the own BVH (shaft path) all the same
     int32_t     per_lane_shaft;   // bit 0: k_shaft (private walks) for the first round instead of k_shaft_pkt, bit 1: for the later rounds instead of k_shaft_coop (cross-checks)
     bool        exact_shadow_tests; // k_shadow_test (every pair in FP64) instead of k_shadow_cls (fp32 classification first)

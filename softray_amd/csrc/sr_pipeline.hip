@@ -1156,39 +1156,58 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
     if (STATS && lane == 0) { atomicAdd(work_count - 2, top21); atomicAdd(work_count - 1, top85); }      // diagnostics: sr_debug_counters [4], [5] (free on the shaft path)
 }
 
-// k_tile_order -- one workgroup per XCD list: a STABLE two-way partition of the list's items (natural ids 0 .. per_xcd - 1) by the walk
-// length k_shaft_pkt4 measured for them: the long walks (>= quarters / 4 times the list's mean; 3 x by default) first, then the others, each part in natural
-// order -- neighbouring tiles share tree nodes and records in the XCD's L2, so the order inside a part is left alone.  A launch
-// ends when its last tile does: with the long walks handed out first, the tiles that remain at the end are short ones.
-__global__ __launch_bounds__(256) void k_tile_order(const unsigned int* __restrict__ cost, unsigned int* __restrict__ order, unsigned int per_xcd, unsigned int quarters) {
+// k_tile_order -- one workgroup per XCD list: a STABLE partition of the list's items (natural ids 0 .. per_xcd - 1) into `classes` classes by the
+// walk length k_shaft_pkt4 measured for them: the longest walks (>= quarters / 4 times the list's mean; 3 x by default) first, then the ones above
+// half that bound, a quarter of it, ... and the rest last, each class in natural order -- neighbouring tiles share tree nodes and records in
+// the XCD's L2, so the order inside a class is left alone.  A launch ends when its last tile does: with the long walks handed out first, the
+// tiles that remain at the end are short ones (two classes: below 3 x the mean; four: below 0.75 x -- what a strip-interleaved part frame
+// with its few tiles per workgroup needs).
+constexpr int kOrderClasses = 4, kOrderWaves = 16;
+__global__ __launch_bounds__(kOrderWaves * 64) void k_tile_order(const unsigned int* __restrict__ cost, unsigned int* __restrict__ order, unsigned int per_xcd, unsigned int quarters,
+                                                    int classes) {
     __shared__ unsigned long long ssum;
-    __shared__ unsigned int wcnt[4];
+    __shared__ unsigned int wcnt[kOrderWaves][kOrderClasses];
     const unsigned int x = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     const unsigned int* c = cost + (size_t)x * per_xcd;
     unsigned int* o = order + (size_t)x * per_xcd;
     if (tid == 0) ssum = 0ull;
     __syncthreads();
     unsigned long long sum = 0ull;
-    for (unsigned int i = tid; i < per_xcd; i += 256u) sum += c[i];
+    for (unsigned int i = tid; i < per_xcd; i += kOrderWaves * 64u) sum += c[i];
     for (int d = 32; d > 0; d >>= 1) sum += __shfl_xor(sum, d, 64);
     if (lane == 0) atomicAdd(&ssum, sum);
     __syncthreads();
-    const unsigned int thr = (unsigned int)min(0xffffffffull, (unsigned long long)quarters * ssum / (4ull * (unsigned long long)max(1u, per_xcd))) + 1u;   // quarters / 4 x the mean
-    // wave w owns a contiguous segment of the list (coalesced batches of 64 items): count its long walks, then place both kinds
-    const unsigned int seg = ((per_xcd + 3u) / 4u + 63u) / 64u * 64u, i0 = min(per_xcd, w * seg), i1 = min(per_xcd, i0 + seg);
-    unsigned int cnt = 0;
+    const unsigned int thr = (unsigned int)min(0xfffffffeull, (unsigned long long)quarters * ssum / (4ull * (unsigned long long)max(1u, per_xcd))) + 1u;   // quarters / 4 x the mean
+    // class of a walk length: 0 for >= thr, k for >= thr >> k, the last class for everything else
+    auto cls_of = [&](unsigned int v) { int k = 0; while (k + 1 < classes && v < (thr >> k)) ++k; return k; };
+    // wave w owns a contiguous segment of the list (coalesced batches of 64 items): count its classes, then place every item
+    const unsigned int seg = ((per_xcd + kOrderWaves - 1u) / kOrderWaves + 63u) / 64u * 64u, i0 = min(per_xcd, w * seg), i1 = min(per_xcd, i0 + seg);
+    unsigned int cnt[kOrderClasses] = {};
     for (unsigned int b = i0; b < i1; b += 256u) {                       // (four batches of 64 in flight: the loop is load latency)
         unsigned int v[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const unsigned int i = b + 64u * u + lane; v[u] = i < i1 ? c[i] : 0u; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) cnt += (unsigned int)__popcll(__ballot(v[u] >= thr));
+        for (int u = 0; u < 4; ++u) {
+            const unsigned int i = b + 64u * u + lane;
+            const int k = i < i1 ? cls_of(v[u]) : -1;
+#pragma unroll
+            for (int q = 0; q < kOrderClasses; ++q) cnt[q] += (unsigned int)__popcll(__ballot(k == q));
+        }
     }
-    if (lane == 0) wcnt[w] = cnt;
+    if (lane == 0) {
+#pragma unroll
+        for (int q = 0; q < kOrderClasses; ++q) wcnt[w][q] = cnt[q];
+    }
     __syncthreads();
-    unsigned int before = 0, nlong = 0;
-    for (unsigned int k = 0; k < 4u; ++k) { const unsigned int v = wcnt[k]; if (k < w) before += v; nlong += v; }
-    unsigned int pl = before, ps = nlong + (i0 - before);
+    unsigned int pos[kOrderClasses], base = 0;
+#pragma unroll
+    for (int q = 0; q < kOrderClasses; ++q) {                            // class q starts after the classes before it; this wave's share after the earlier waves'
+        unsigned int before = 0, all = 0;
+        for (unsigned int k = 0; k < (unsigned int)kOrderWaves; ++k) { const unsigned int v = wcnt[k][q]; if (k < w) before += v; all += v; }
+        pos[q] = base + before;
+        base += all;
+    }
     for (unsigned int b = i0; b < i1; b += 256u) {
         unsigned int v[4];
 #pragma unroll
@@ -1196,11 +1215,14 @@ __global__ __launch_bounds__(256) void k_tile_order(const unsigned int* __restri
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const unsigned int i = b + 64u * u + lane;
-            const bool in = i < i1, lg = in && v[u] >= thr;
-            const unsigned long long ml = __ballot(lg), ms = __ballot(in && !lg), lt = lanemask_lt();
-            if (lg) o[pl + (unsigned int)__popcll(ml & lt)] = i;
-            else if (in) o[ps + (unsigned int)__popcll(ms & lt)] = i;
-            pl += (unsigned int)__popcll(ml); ps += (unsigned int)__popcll(ms);
+            const int k = i < i1 ? cls_of(v[u]) : -1;
+            const unsigned long long lt = lanemask_lt();
+#pragma unroll
+            for (int q = 0; q < kOrderClasses; ++q) {
+                const unsigned long long m = __ballot(k == q);
+                if (k == q) o[pos[q] + (unsigned int)__popcll(m & lt)] = i;
+                pos[q] += (unsigned int)__popcll(m);
+            }
         }
     }
 }
@@ -3435,7 +3457,7 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                 if (tn2 > 0) blocks = (unsigned)(xcd_tile_grid(L.fc.width, trows) * tn2);      // the grid of k_primary (x sub-samples)
                 unsigned int* heads;
                 const unsigned vblocks = blocks;
-                blocks = tile_grid(L, vblocks, (L.fc.debug >= 830 && L.fc.debug <= 836) ? L.fc.debug - 830 : 6, L.counters + kHeadsShaft, &heads);          // ... or the resident grid pulling its tiles (hook 830 + n: n workgroups per CU)
+                blocks = tile_grid(L, vblocks, (L.fc.debug >= 830 && L.fc.debug <= 836) ? L.fc.debug - 830 : (L.shaft_wgs_per_cu > 0 ? L.shaft_wgs_per_cu : 6), L.counters + kHeadsShaft, &heads);          // ... or the resident grid pulling its tiles (hook 830 + n: n workgroups per CU)
                 // (persistent) longest walks first: the lists k_tile_order made from the previous frame's walk lengths, if that frame had this tile grid
                 const unsigned long long order_tag = ((unsigned long long)vblocks << 32) | ((unsigned long long)(unsigned)L.fc.width << 12) | (unsigned long long)(unsigned)tn2;
                 const bool keep_cost = heads && L.tile_cost && L.tile_order && L.tile_order_tag && L.fc.debug != 84;
@@ -3541,8 +3563,9 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
     if (e1 && (e = hipEventRecord(e1, L.stream)) != hipSuccess) return e;
     // the next frame's longest-first tile lists, from this frame's walk lengths: last in the stage (nothing of this frame waits for it)
     if (order_items) {
-        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(256), 0, L.stream, (const unsigned int*)L.tile_cost, L.tile_order, order_items,
-                           (L.fc.debug >= 840 && L.fc.debug < 880) ? (unsigned)(L.fc.debug - 840) : 12u);   // long = >= 3 x the mean (2 x: 1.41 ms per rank of 8, 3 x: 1.37, 4 x: 1.40)
+        hipLaunchKernelGGL(k_tile_order, dim3(8), dim3(kOrderWaves * 64), 0, L.stream, (const unsigned int*)L.tile_cost, L.tile_order, order_items,
+                           (L.fc.debug >= 840 && L.fc.debug < 880) ? (unsigned)(L.fc.debug - 840) : 12u,   // longest = >= 3 x the mean (2 x: 1.41 ms per rank of 8, 3 x: 1.37, 4 x: 1.40)
+                           (L.fc.debug > 880 && L.fc.debug <= 880 + kOrderClasses) ? L.fc.debug - 880 : 3);   // classes (hook 880 + n): 2 / 3 / 4: slowest rank of 8 1.40 / 1.31 / 1.32 ms at 3 workgroups per CU (1.37 / 1.40 / 1.42 at 6)
         if ((e = hipGetLastError()) != hipSuccess) return e;
         *L.tile_order_tag = order_new_tag;
     }

@@ -178,6 +178,11 @@ def test_product_host_helpers_match_oracle():
     assert sa.default_fov_depth() == orc.default_fov_depth()
     for seed in (1234567890, 1, -5, 2147483647):
         assert np.array_equal(sa.area_light_offsets(seed, 100), orc.area_light_offsets(seed, 100))
+    # the ray generator of the micro-benchmarks (sr_net_random_doubles) is the same System.Random stream, with and without a skip
+    for seed in (12345, 1, -7):
+        want = orc.Random(seed).NextDoubles(300)
+        assert np.array_equal(sa.net_random_doubles(seed, 300), want)
+        assert np.array_equal(sa.net_random_doubles(seed, 100, skip=200), want[200:])
 
 
 def test_product_scene_generator_matches_reference_generator():
