@@ -540,6 +540,10 @@ __device__ __forceinline__ ShaftRay make_shaft_ray(const DevScene& sc, const Fra
 
 // returns 0: no sample ray can hit the triangle; 1: candidate; 2: UMBRA.  Straight-line code (the kernels that call it are
 // bound by instruction issue, scalar bookkeeping of nested branches included); `want`: lanes whose verdict is looked at.
+// STAGED (the packet walks: all lanes test the SAME triangle with the shafts of one 8x8-pixel tile): the wave leaves after the
+// first edge plane that has every lane's shaft on its outside.  Census of the headline frame: of 16.0 M wave-level filters 9.9 M get
+// past the plane stage; 5.6 M of those end at the first edge, 1.5 M at the second, 0.9 M at the third, 1.9 M leave a candidate.
+template <bool STAGED = false>
 __device__ __forceinline__ int shaft_touches(const TriSlab s, const ShaftRay& sr, bool want) {
     // (f0, f1) of the plane and the three edge planes along the centre ray, two lanes per packed FMA
     f2 cn = {-s.d, 0.0f}, c1 = {-s.c1, 0.0f}, c2 = {-s.c2, 0.0f}, c3 = {-s.c3, 0.0f};
@@ -550,16 +554,20 @@ __device__ __forceinline__ int shaft_touches(const TriSlab s, const ShaftRay& sr
     // every sample starts behind the plane
     const bool plane_ok = want && !(N1 < -sr.backface) && !(G0 > sr.a0) && !(G0 + N1 + sr.R < -sr.a01);
     if (__ballot(plane_ok) == 0ull) return 0;                          // (wave-level: nobody is left)
-    const f2 P = pk_fma(splat(s.m1[0]), sr.edx, pk_fma(splat(s.m1[1]), sr.edy, pk_fma(splat(s.m1[2]), sr.edz, c1)));
-    const f2 Q = pk_fma(splat(s.m2[0]), sr.edx, pk_fma(splat(s.m2[1]), sr.edy, pk_fma(splat(s.m2[2]), sr.edz, c2)));
-    const f2 T = pk_fma(splat(s.m3[0]), sr.edx, pk_fma(splat(s.m3[1]), sr.edy, pk_fma(splat(s.m3[2]), sr.edz, c3)));
     const float g2 = G0 * G0, ag = fabsf(G0);
-    const float A1 = __builtin_fmaf(P.x, N1, -(G0 * P.y)), A2 = __builtin_fmaf(Q.x, N1, -(G0 * Q.y)), A3 = __builtin_fmaf(T.x, N1, -(G0 * T.y));
-    const float L1 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(P.x, P.x, g2)), L2 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(Q.x, Q.x, g2)),
-                L3 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(T.x, T.x, g2));
-    const float e1 = __builtin_fmaf(sr.c1, fabsf(P.x) + ag, sr.c0), e2 = __builtin_fmaf(sr.c1, fabsf(Q.x) + ag, sr.c0), e3 = __builtin_fmaf(sr.c1, fabsf(T.x) + ag, sr.c0);
-    // some direction of the ball inside every edge (each edge on its own)
-    const bool cand = plane_ok && !(fminf(fminf(A1 + L1 + e1, A2 + L2 + e2), A3 + L3 + e3) < 0.0f);
+    // some direction of the ball inside every edge (each edge on its own): A_k + R L_k + eps_k >= 0
+    const f2 P = pk_fma(splat(s.m1[0]), sr.edx, pk_fma(splat(s.m1[1]), sr.edy, pk_fma(splat(s.m1[2]), sr.edz, c1)));
+    const float A1 = __builtin_fmaf(P.x, N1, -(G0 * P.y)), L1 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(P.x, P.x, g2)), e1 = __builtin_fmaf(sr.c1, fabsf(P.x) + ag, sr.c0);
+    const bool ok1 = plane_ok && !(A1 + L1 + e1 < 0.0f);
+    if (STAGED && __ballot(ok1) == 0ull) return 0;
+    const f2 Q = pk_fma(splat(s.m2[0]), sr.edx, pk_fma(splat(s.m2[1]), sr.edy, pk_fma(splat(s.m2[2]), sr.edz, c2)));
+    const float A2 = __builtin_fmaf(Q.x, N1, -(G0 * Q.y)), L2 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(Q.x, Q.x, g2)), e2 = __builtin_fmaf(sr.c1, fabsf(Q.x) + ag, sr.c0);
+    const bool ok2 = ok1 && !(A2 + L2 + e2 < 0.0f);
+    if (STAGED && __ballot(ok2) == 0ull) return 0;
+    const f2 T = pk_fma(splat(s.m3[0]), sr.edx, pk_fma(splat(s.m3[1]), sr.edy, pk_fma(splat(s.m3[2]), sr.edz, c3)));
+    const float A3 = __builtin_fmaf(T.x, N1, -(G0 * T.y)), L3 = sr.Rm * __builtin_amdgcn_sqrtf(__builtin_fmaf(T.x, T.x, g2)), e3 = __builtin_fmaf(sr.c1, fabsf(T.x) + ag, sr.c0);
+    const bool cand = ok2 && !(A3 + L3 + e3 < 0.0f);
+    if (STAGED && __ballot(cand) == 0ull) return 0;
     // ---- umbra: every direction of the ball inside every edge ----
     const bool pre = cand && fminf(fminf(A1 - L1 - e1, A2 - L2 - e2), A3 - L3 - e3) > 0.0f && N1 > 2.0f * sr.Rm + sr.a01 && G0 < -4.0f * sr.a0;
     bool umbra = false;
@@ -932,7 +940,7 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc
                 for (int q = 0; q < cn; ++q) {
                     const TriSlab s = sc.bslab[cc + q];               // scalar load
                     const bool live_q = hc && !done;
-                    const int touch = shaft_touches(s, sr, live_q);
+                    const int touch = shaft_touches<true>(s, sr, live_q);
                     const bool take = live_q && touch != 0, room = count < cap;
                     if (take && room) out[count] = cc + q;
                     count += (take && room) ? 1 : 0;
@@ -1095,7 +1103,7 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
             for (int q = 0; q < cn; ++q) {
                 const TriSlab s = load_uniform(&sc_arg.bslab[cc + q]); // scalar load
                 const bool live_q = hc && !done;
-                const int touch = shaft_touches(s, sr, live_q);
+                const int touch = shaft_touches<true>(s, sr, live_q);
                 const bool take = live_q && touch != 0, room = count < cap;
                 if (take && room) out[count] = cc + q;
                 count += (take && room) ? 1 : 0;
