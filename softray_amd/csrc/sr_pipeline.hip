@@ -987,6 +987,16 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc
     }
 }
 
+// the slab test of one child of the LIGHT-ordered copy (plane pairs (lo.x, lo.y), (hi.x, hi.y), (lo.z, hi.z) in the slots lo[0..1], (lo[2], hi[0]),
+// hi[1..2]: k_order_nodes): child_slabs' arithmetic -- the same products, the same sums -- with the pairs that need two reciprocal vectors only
+__device__ __forceinline__ void shaft_slabs(const Bvh4Child& ch, f2 Ixy, f2 Izz, f2 B0, f2 B1, f2 B2, float& a, float& b) {
+    const f2 T0 = pk_fma((f2){ch.lo[0], ch.lo[1]}, Ixy, B0), T1 = pk_fma((f2){ch.lo[2], ch.hi[0]}, Ixy, B1), T2 = pk_fma((f2){ch.hi[1], ch.hi[2]}, Izz, B2);
+    // fminf/fmaxf drop a NaN operand: conservative
+    const float nx = fminf(T0.x, T1.x), fx = fmaxf(T0.x, T1.x), ny = fminf(T0.y, T1.y), fy = fmaxf(T0.y, T1.y), nz = fminf(T2.x, T2.y), fz = fmaxf(T2.x, T2.y);
+    a = fmaxf(fmaxf(nx, ny), nz);
+    b = fminf(fminf(fx, fy), fz);
+}
+
 // --------------------------------------------------------------------------------------------------
 // k_shaft_pkt4 -- the same packet walk on the FOUR-WIDE tree (Bvh4Node): a step fetches one 128-byte node (one pair of scalar
 // loads) and tests four children's boxes, so a tile's walk is about half as many dependent steps, scalar-cache round trips and
@@ -1052,16 +1062,21 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
     const float ex = (float)(E.x - sc.root.centre[0]), ey = (float)(E.y - sc.root.centre[1]), ez = (float)(E.z - sc.root.centre[2]);
     const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
     const float ix = slab_inv(dx), iy = slab_inv(dy), iz = slab_inv(dz);
-    const f2 I01 = {ix, iy}, I20 = {iz, ix}, I12 = {iy, iz};
-    const f2 OI01 = {-ex * ix, -ey * iy}, OI20 = {-ez * iz, -ex * ix}, OI12 = {-ey * iy, -ez * iz};
-    const f2 RI01 = {-ix, -iy}, RI20 = {-iz, ix}, RI12 = {iy, iz};
+    const f2 Ixy = {ix, iy}, Izz = {iz, iz};                           // (the light-ordered copy's plane pairs: see k_order_nodes)
+    const f2 Oxy = {-ex * ix, -ey * iy}, Ozz = splat(-ez * iz);
     const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
     const ShaftRay sr = make_shaft_ray(sc, fc, E, lpos);
     int32_t* out = cand + (size_t)slot_i * cap;
     int count = 0;
     bool truncated = false, umbra = false;
     bool done = !valid;
-    int sp = 0;                      // wave-uniform
+    int sp = 0;                      // wave-uniform: entries in LDS
+    // the TOP of the stack lives in registers (node: wave-uniform, bound: one encoded 16-bit value per lane): most nodes of the lowest inner level
+    // have leaf children only, so every other step ends in a pop -- two dependent LDS reads (the lanes' bounds, then the node) before the next node
+    // can even be requested.  With the top in registers a pop is immediate and the entry below it is fetched while the popped subtree's node is on its way.
+    bool has_top = false;            // wave-uniform
+    int32_t top_ni = 0;              // the same value in every lane (a vector register: the LDS read that refills it is not waited for)
+    uint32_t top_b = 0u;             // this lane's encoded u bound of the top entry
     int32_t ni = 0;                  // wave-uniform: current inner node
     float nu = valid ? 1.0f : -1.0f; // this lane's u bound inside the current subtree; < 0: the lane's shaft misses it
     auto enc = [](float fb) { return fb < 0.0f ? (uint16_t)0 : (uint16_t)min(65535, (int)(fminf(fb, 1.0f) * 65534.0f) + 2); };
@@ -1070,11 +1085,13 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
             if (__ballot(!done) == 0ull) break;                        // every lane has its verdict: nothing on the stack matters
             // nobody wants the current subtree: pop until a live lane wants one
             bool found = false;
-            while (sp > 0) {
-                --sp;
-                const uint32_t qb = wbound[sp * 64];
+            while (has_top) {
+                const uint32_t qb = top_b;
+                const int32_t qn = top_ni;
+                if (sp > 0) { --sp; top_b = wbound[sp * 64]; top_ni = wnode[sp]; }      // (the entry below: needed at the next pop, so nothing waits for these two reads here)
+                else has_top = false;
                 const float bu = qb ? (float)(qb - 1u) * (1.0f / 65534.0f) * 1.000001f : -1.0f;
-                if (__ballot(!done && bu >= 0.0f) != 0ull) { ni = __builtin_amdgcn_readfirstlane(wnode[sp]); nu = bu; found = true; break; }
+                if (__ballot(!done && bu >= 0.0f) != 0ull) { ni = __builtin_amdgcn_readfirstlane(qn); nu = bu; found = true; break; }
             }
             if (!found) break;
         }
@@ -1082,13 +1099,16 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
         nodes++;
         if (STATS) { top21 += ni < 21 ? 1u : 0u; top85 += ni < 85 ? 1u : 0u; }
         if (PERSIST) walk += 2u;
-        const f2 rr = splat(__builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad));
-        const f2 B0 = pk_fma(rr, RI01, OI01), B1 = pk_fma(rr, RI20, OI20), B2 = pk_fma(rr, RI12, OI12);
+        // the shaft's radius moves a box's lo planes by -r and its hi planes by +r: (lo.x, lo.y), (hi.x, hi.y), (lo.z, hi.z) against the same
+        // reciprocals the planes are multiplied with (no second set of per-lane constants kept across the walk)
+        const float rs = __builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad);
+        const f2 rr = splat(rs), rn = splat(-rs), rm = {-rs, rs};
+        const f2 B0 = pk_fma(rn, Ixy, Oxy), B1 = pk_fma(rr, Ixy, Oxy), B2 = pk_fma(rm, Izz, Ozz);
         float a0, b0, a1, b1, a2, b2, a3, b3;                          // child u-intervals [a, b] of this lane's shaft
-        child_slabs(n.ch[0], I01, I20, I12, B0, B1, B2, a0, b0);
-        child_slabs(n.ch[1], I01, I20, I12, B0, B1, B2, a1, b1);
-        child_slabs(n.ch[2], I01, I20, I12, B0, B1, B2, a2, b2);
-        child_slabs(n.ch[3], I01, I20, I12, B0, B1, B2, a3, b3);
+        shaft_slabs(n.ch[0], Ixy, Izz, B0, B1, B2, a0, b0);
+        shaft_slabs(n.ch[1], Ixy, Izz, B0, B1, B2, a1, b1);
+        shaft_slabs(n.ch[2], Ixy, Izz, B0, B1, B2, a2, b2);
+        shaft_slabs(n.ch[3], Ixy, Izz, B0, B1, B2, a3, b3);
         b0 = fminf(b0, nu); b1 = fminf(b1, nu); b2 = fminf(b2, nu); b3 = fminf(b3, nu);
         const bool h0 = !done && n.ch[0].n >= 0 && fmaxf(a0, umin) <= b0, h1 = !done && n.ch[1].n >= 0 && fmaxf(a1, umin) <= b1;
         const bool h2 = !done && n.ch[2].n >= 0 && fmaxf(a2, umin) <= b2, h3 = !done && n.ch[3].n >= 0 && fmaxf(a3, umin) <= b3;
@@ -1119,22 +1139,26 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
         // ---- inner children, far to near: the nearest one a live lane wants is entered, the others wait on the stack ----
         int32_t next = -1;
         float next_u = -1.0f;
+        const auto push = [&](const int32_t pn, const float pu) __attribute__((always_inline)) {
+            if (has_top) { wnode[sp] = top_ni; wbound[sp * 64] = (uint16_t)top_b; sp++; }      // the old top moves to LDS
+            top_ni = pn; top_b = (uint32_t)enc(pu); has_top = true;
+        };
         {
             const bool w3 = h3 && !done && n.ch[3].n == 0;
             if (__ballot(w3) != 0ull) { next = n.ch[3].c; next_u = w3 ? b3 : -1.0f; }
             const bool w2 = h2 && !done && n.ch[2].n == 0;
             if (__ballot(w2) != 0ull) {
-                if (next >= 0) { wnode[sp] = next; wbound[sp * 64] = enc(next_u); sp++; }
+                if (next >= 0) push(next, next_u);
                 next = n.ch[2].c; next_u = w2 ? b2 : -1.0f;
             }
             const bool w1 = h1 && !done && n.ch[1].n == 0;
             if (__ballot(w1) != 0ull) {
-                if (next >= 0) { wnode[sp] = next; wbound[sp * 64] = enc(next_u); sp++; }
+                if (next >= 0) push(next, next_u);
                 next = n.ch[1].c; next_u = w1 ? b1 : -1.0f;
             }
             const bool w0 = h0 && !done && n.ch[0].n == 0;
             if (__ballot(w0) != 0ull) {
-                if (next >= 0) { wnode[sp] = next; wbound[sp * 64] = enc(next_u); sp++; }
+                if (next >= 0) push(next, next_u);
                 next = n.ch[0].c; next_u = w0 ? b0 : -1.0f;
             }
         }
@@ -3326,6 +3350,15 @@ __global__ __launch_bounds__(256) void k_order_nodes(const Bvh4Node* __restrict_
 #pragma unroll
         for (int a = 0; a < 3; ++a)
             if ((swap_mask >> a) & 1) { const float t = nd.ch[k].lo[a]; nd.ch[k].lo[a] = nd.ch[k].hi[a]; nd.ch[k].hi[a] = t; }
+    // the light-ordered copy keeps a child's planes as (lo.x, lo.y), (hi.x, hi.y), (lo.z, hi.z): k_shaft_pkt4's packed slab test then needs the
+    // reciprocals (ix, iy) and (iz, iz) only -- four per-lane constants less across its walk than with (lo.x, lo.y), (lo.z, hi.x), (hi.y, hi.z)
+    if (far_first) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float lz = nd.ch[k].lo[2], hx = nd.ch[k].hi[0], hy = nd.ch[k].hi[1];
+            nd.ch[k].lo[2] = hx; nd.ch[k].hi[0] = hy; nd.ch[k].hi[1] = lz;
+        }
+    }
     out[i] = nd;
 }
 
