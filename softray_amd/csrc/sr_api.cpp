@@ -571,9 +571,12 @@ int render_common(sr_scene* s, const sr_frame* f, uint32_t* d_pixels, hipStream_
         if (!s->b4light_valid || !same_light) {                       // ... and nearest-to-the-surface first for this light
             rewrote = true;
             s->b4light_valid = false;
-            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4light.p, (int)s->b4_num, s->root, fc.light_pos_model, true, 0,
+            int known, beyond;                                    // (a light BELOW the box on an axis: every shaft travels towards smaller coordinates there, hi first)
+            point_outside_axes(s->root, fc.light_pos_model, known, beyond);
+            if (s->dbg[SR_DBG_KERNEL_SWITCH] == 62) known = 0;                    // (hook: (lo, hi) planes on every axis)
+            SR_HIP(sr::launch_order_nodes((const sr::Bvh4Node*)s->d_b4.p, (sr::Bvh4Node*)s->d_b4light.p, (int)s->b4_num, s->root, fc.light_pos_model, true, known & ~beyond,
                                           (s->part_valid && s->part_light) ? s->d_rng_light.p : nullptr, stream));
-            s->b4light_known = 0;
+            s->b4light_known = known;
             for (int i = 0; i < 3; ++i) s->b4_light[i] = fc.light_pos_model[i];
             s->b4light_valid = true;
         }

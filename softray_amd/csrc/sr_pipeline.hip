@@ -14,6 +14,7 @@
 #include "sr_trace.h"
 
 #include <algorithm>
+#include <type_traits>
 
 namespace sr {
 
@@ -989,10 +990,13 @@ __global__ __launch_bounds__(256, 7) void k_shaft_pkt(DevScene sc, FrameConst fc
 
 // the slab test of one child of the LIGHT-ordered copy (plane pairs (lo.x, lo.y), (hi.x, hi.y), (lo.z, hi.z) in the slots lo[0..1], (lo[2], hi[0]),
 // hi[1..2]: k_order_nodes): child_slabs' arithmetic -- the same products, the same sums -- with the pairs that need two reciprocal vectors only
+template <int KNOWN = 0>
 __device__ __forceinline__ void shaft_slabs(const Bvh4Child& ch, f2 Ixy, f2 Izz, f2 B0, f2 B1, f2 B2, float& a, float& b) {
     const f2 T0 = pk_fma((f2){ch.lo[0], ch.lo[1]}, Ixy, B0), T1 = pk_fma((f2){ch.lo[2], ch.hi[0]}, Ixy, B1), T2 = pk_fma((f2){ch.hi[1], ch.hi[2]}, Izz, B2);
     // fminf/fmaxf drop a NaN operand: conservative
-    const float nx = fminf(T0.x, T1.x), fx = fmaxf(T0.x, T1.x), ny = fminf(T0.y, T1.y), fy = fmaxf(T0.y, T1.y), nz = fminf(T2.x, T2.y), fz = fmaxf(T2.x, T2.y);
+    const float nx = (KNOWN & 1) ? T0.x : fminf(T0.x, T1.x), fx = (KNOWN & 1) ? T1.x : fmaxf(T0.x, T1.x);
+    const float ny = (KNOWN & 2) ? T0.y : fminf(T0.y, T1.y), fy = (KNOWN & 2) ? T1.y : fmaxf(T0.y, T1.y);
+    const float nz = (KNOWN & 4) ? T2.x : fminf(T2.x, T2.y), fz = (KNOWN & 4) ? T2.y : fmaxf(T2.x, T2.y);
     a = fmaxf(fmaxf(nx, ny), nz);
     b = fminf(fminf(fx, fy), fz);
 }
@@ -1007,7 +1011,7 @@ __device__ __forceinline__ void shaft_slabs(const Bvh4Child& ch, f2 Ixy, f2 Izz,
 // the candidate lists may differ in order and in which candidates a truncated list holds, which no later stage depends on.
 // LDS per wave: [levels] node words + [levels][64] 16-bit bounds, levels = 3 * b4depth + 2.
 // --------------------------------------------------------------------------------------------------
-template <bool STATS, int WAVES, bool PERSIST>
+template <bool STATS, int WAVES, bool PERSIST, int KNOWN = 0>
 __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, FrameConst fc_arg, const HitRec* __restrict__ hits,
                                                     const unsigned int* __restrict__ hit_count, int cap, int levels, int tile_n2, int tile_rows,
                                                     unsigned int* __restrict__ cand_count, int32_t* __restrict__ cand,
@@ -1063,6 +1067,9 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
     const float dx = (float)(lpos.x - E.x), dy = (float)(lpos.y - E.y), dz = (float)(lpos.z - E.z);
     const float ix = slab_inv(dx), iy = slab_inv(dy), iz = slab_inv(dz);
     const f2 Ixy = {ix, iy}, Izz = {iz, iz};                           // (the light-ordered copy's plane pairs: see k_order_nodes)
+    // sign of the shafts' direction on the axes where the light lies outside the root box (wave-uniform; |i| = s i there)
+    const float known_sx = fc.light_pos_model[0] > sc.root.centre[0] ? 1.0f : -1.0f, known_sy = fc.light_pos_model[1] > sc.root.centre[1] ? 1.0f : -1.0f,
+                known_sz = fc.light_pos_model[2] > sc.root.centre[2] ? 1.0f : -1.0f;
     const f2 Oxy = {-ex * ix, -ey * iy}, Ozz = splat(-ez * iz);
     const float umin = -1e-5f;                                         // hits with rayFrac rounding just beyond 1.0
     const ShaftRay sr = make_shaft_ray(sc, fc, E, lpos);
@@ -1102,13 +1109,15 @@ __global__ __launch_bounds__(256, WAVES) void k_shaft_pkt4(DevScene sc_arg, Fram
         // the shaft's radius moves a box's lo planes by -r and its hi planes by +r: (lo.x, lo.y), (hi.x, hi.y), (lo.z, hi.z) against the same
         // reciprocals the planes are multiplied with (no second set of per-lane constants kept across the walk)
         const float rs = __builtin_fmaf(R, fminf(1.0f, fmaxf(0.0f, nu + 1e-5f)), pad);
-        const f2 rr = splat(rs), rn = splat(-rs), rm = {-rs, rs};
+        // (on a KNOWN axis the copy holds (near, far): the near plane moves by -r |i|, the far plane by +r |i|; the sign of i is the frame's there)
+        const float rx = (KNOWN & 1) ? rs * known_sx : rs, ry = (KNOWN & 2) ? rs * known_sy : rs, rz = (KNOWN & 4) ? rs * known_sz : rs;
+        const f2 rr = {rx, ry}, rn = {-rx, -ry}, rm = {-rz, rz};
         const f2 B0 = pk_fma(rn, Ixy, Oxy), B1 = pk_fma(rr, Ixy, Oxy), B2 = pk_fma(rm, Izz, Ozz);
         float a0, b0, a1, b1, a2, b2, a3, b3;                          // child u-intervals [a, b] of this lane's shaft
-        shaft_slabs(n.ch[0], Ixy, Izz, B0, B1, B2, a0, b0);
-        shaft_slabs(n.ch[1], Ixy, Izz, B0, B1, B2, a1, b1);
-        shaft_slabs(n.ch[2], Ixy, Izz, B0, B1, B2, a2, b2);
-        shaft_slabs(n.ch[3], Ixy, Izz, B0, B1, B2, a3, b3);
+        shaft_slabs<KNOWN>(n.ch[0], Ixy, Izz, B0, B1, B2, a0, b0);
+        shaft_slabs<KNOWN>(n.ch[1], Ixy, Izz, B0, B1, B2, a1, b1);
+        shaft_slabs<KNOWN>(n.ch[2], Ixy, Izz, B0, B1, B2, a2, b2);
+        shaft_slabs<KNOWN>(n.ch[3], Ixy, Izz, B0, B1, B2, a3, b3);
         b0 = fminf(b0, nu); b1 = fminf(b1, nu); b2 = fminf(b2, nu); b3 = fminf(b3, nu);
         const bool h0 = !done && n.ch[0].n >= 0 && fmaxf(a0, umin) <= b0, h1 = !done && n.ch[1].n >= 0 && fmaxf(a1, umin) <= b1;
         const bool h2 = !done && n.ch[2].n >= 0 && fmaxf(a2, umin) <= b2, h3 = !done && n.ch[3].n >= 0 && fmaxf(a3, umin) <= b3;
@@ -3510,8 +3519,22 @@ static hipError_t launch_shadow_t(const PipelineLaunch& L, uint32_t* samples, lo
                 // 6 waves/SIMD (85 VGPRs): 5.16 ms on the headline frame; 7 waves (72 VGPRs, spills in the node step) 5.44; 5 waves 5.61
                 // ((near, far) planes in the light-ordered copy, as in the camera-ordered one, were measured: fewer instructions, more spills at
                 //  this kernel's register budget -- 5.17 -> 5.30 ms; 5.49 ms at 5 waves/SIMD)
-                if (heads) { if (L.stats) go(k_shaft_pkt4<true, 6, true>); else go(k_shaft_pkt4<false, 6, true>); }
-                else { if (L.stats) go(k_shaft_pkt4<true, 6, false>); else go(k_shaft_pkt4<false, 6, false>); }
+                // one instantiation per set of axes on which the light-ordered copy holds (near, far) planes (the light lies outside the root box there)
+                const auto go_known = [&](auto known) {
+                    constexpr int K = decltype(known)::value;
+                    if (heads) { if (L.stats) go(k_shaft_pkt4<true, 6, true, K>); else go(k_shaft_pkt4<false, 6, true, K>); }
+                    else { if (L.stats) go(k_shaft_pkt4<true, 6, false, K>); else go(k_shaft_pkt4<false, 6, false, K>); }
+                };
+                switch (L.sc.b4light_known & 7) {
+                    case 1: go_known(std::integral_constant<int, 1>()); break;
+                    case 2: go_known(std::integral_constant<int, 2>()); break;
+                    case 3: go_known(std::integral_constant<int, 3>()); break;
+                    case 4: go_known(std::integral_constant<int, 4>()); break;
+                    case 5: go_known(std::integral_constant<int, 5>()); break;
+                    case 6: go_known(std::integral_constant<int, 6>()); break;
+                    case 7: go_known(std::integral_constant<int, 7>()); break;
+                    default: go_known(std::integral_constant<int, 0>()); break;
+                }
                 if (keep_cost) { order_items = (vblocks >> 3) * 4u; order_new_tag = order_tag; }
             } else if (first && !(L.per_lane_shaft & 1)) {
                 // round 1 on the binary tree (cross-check): one packet walk per 64 consecutive queue entries (one 8x8-pixel tile when the queue is tile-aligned)

@@ -64,6 +64,9 @@ def frame_of(c):
     dx, dy, dz = f.light_dir_view[0], f.light_dir_view[1], f.light_dir_view[2]
     f.light_dir_view[0], f.light_dir_view[1], f.light_dir_view[2] = ca * dx - sn * dy, sn * dx + ca * dy, dz
     f.max_bounces, f.reflectivity = c["bounces"], c["reflectivity"]
+    if "light_view" in c:
+        for i in range(3):
+            f.light_pos_view[i] = c["light_view"][i]
     return f
 
 
@@ -105,6 +108,23 @@ def test_random_large_frame_on_the_persistent_shaft_walk(seed):
     got, want = run_case(c)
     bad = np.flatnonzero(got != want)
     assert bad.size == 0, "%d pixels differ (first %s) in %r" % (bad.size, bad[:5], c)
+
+
+@pytest.mark.parametrize("mask", range(8))
+@pytest.mark.parametrize("below", [0, 7, 5])
+def test_light_outside_the_box_on_every_subset_of_axes(mask, below):
+    """The light-ordered node copy holds (near, far) planes on the axes where the light lies outside the scene's box (one instantiation of the
+    shaft walk per subset); `below`: the axes on which it lies on the negative side."""
+    c = case_of(4242 + mask)
+    c.update(n=3000, extent=0.08, res=(200, 144), shadows=True, samples=33, spp=1, bounces=0, point_light=True, light_scale=1.0, light_turn=0.0,
+             yaw=135.0, pitch=-22.0, roll=0.0, depth=1.3, on_device=True, leaf=4)
+    model = [((-1.1 if (below >> a) & 1 else 1.2) if (mask >> a) & 1 else (-0.3 if (below >> a) & 1 else 0.25)) for a in range(3)]
+    f0 = frame_of(c)
+    t = [f0.transform[i] for i in range(12)]
+    c["light_view"] = [t[4 * r] * model[0] + t[4 * r + 1] * model[1] + t[4 * r + 2] * model[2] + t[4 * r + 3] for r in range(3)]
+    got, want = run_case(c)
+    bad = np.flatnonzero(got != want)
+    assert bad.size == 0, "%d pixels differ (first %s), light at %r in model space" % (bad.size, bad[:5], model)
 
 
 if __name__ == "__main__":
