@@ -167,8 +167,10 @@ __device__ __forceinline__ T tile_arg(const T& plain, size_t offset) {
 // PKT = 2: the packet walk on the four-wide tree's camera-ordered copy (bvh4_packet_nearest), the default; PKT = 3: the same with the
 // camera outside the root box's slab on all three axes (the copy holds (near, far) planes: no min / max per axis); PKT = 1: on the
 // binary tree with a per-step vote (cross-check)
+// (the packet walk on the four-wide tree at 7 waves/SIMD, 72 VGPRs: the kernel waits for its scalar loads -- 68 % VALU busy -- and a seventh wave per SIMD hides more
+//  of them than the handful of spilled registers costs: 2.30 -> 2.25 ms; 8 waves, 64 VGPRs: 2.89)
 template <int MODE, bool EXTRA, bool STATS, bool SUB, int PKT, bool PERSIST>
-__global__ __launch_bounds__(256, SUB ? 5 : 6) void k_primary(DevScene sc_arg, FrameConst fc_arg, const int32_t* __restrict__ row_map, int row_begin,
+__global__ __launch_bounds__(256, SUB ? 5 : ((PKT >= 2 && !PERSIST) ? 7 : 6)) void k_primary(DevScene sc_arg, FrameConst fc_arg, const int32_t* __restrict__ row_map, int row_begin,
                                                  int row_count, uint32_t* __restrict__ samples, HitRec* __restrict__ hits,
                                                  unsigned int* __restrict__ hit_count, uint32_t* __restrict__ bounce_levels,
                                                  uint8_t* __restrict__ bounce_nlev, unsigned long long* stats, int pad_tiles, int levels,
