@@ -130,8 +130,9 @@ def test_light_outside_the_box_on_every_subset_of_axes(mask, below):
 if __name__ == "__main__":
     count = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"            # python tests/test_gpu_fuzz.py 40 100 big: the large persistent-walk cases
     for seed in range(first, first + count):
-        c = case_of(seed)
+        c = big_case_of(seed) if big else case_of(seed)
         got, want = run_case(c)
         bad = np.flatnonzero(got != want)
         print(seed, "ok" if bad.size == 0 else "DIFFERENT %d" % bad.size, c, flush=True)
