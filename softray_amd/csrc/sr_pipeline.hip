@@ -3074,9 +3074,16 @@ __global__ __launch_bounds__(256) void k_bounce_finish(DevScene sc, FrameConst f
     const unsigned int total = *qin_count, stride = gridDim.x * 256u;
     const int maxb = fc.max_bounces;
     uint32_t n_geom = 0;
-    for (unsigned int r0 = blockIdx.x * 256u; r0 < total; r0 += stride) {          // whole waves stay in the loop (the queue append is wave-aggregated)
+    // The queue append is aggregated per WORKGROUP: one atomicAdd on the queue's counter per 256 rays.  One per wave -- 160 k atomics on one address
+    // per level at 10 M rays -- is what the kernel's time was: the L2 serialises them.
+    __shared__ unsigned int s_cnt[2][4], s_base[2];
+    const unsigned int lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    unsigned int parity = 0u;
+    for (unsigned int r0 = blockIdx.x * 256u; r0 < total; r0 += stride, parity ^= 1u) {   // whole workgroups stay in the loop
         const unsigned int r = r0 + threadIdx.x;
-        if (r >= total) continue;
+        bool append = false;
+        HitRec o;
+        if (r < total) {
         const BounceRay p = prep[r];
         const BounceHit h = res[r];
         const D3 s = mk(p.s[0], p.s[1], p.s[2]), d = mk(p.d[0], p.d[1], p.d[2]);
@@ -3117,15 +3124,28 @@ __global__ __launch_bounds__(256) void k_bounce_finish(DevScene sc, FrameConst f
                 nlev[sample] = (uint8_t)(nl | 0x80u);                  // the deepest level is a surface: nothing beyond it
             } else {
                 nlev[sample] = (uint8_t)nl;
-                HitRec o;
                 const D3 refl = d - hnrm * (2.0 * dot(d, hnrm));
                 const D3 org = hpos + hnrm * 0.001;
                 o.pos[0] = org.x; o.pos[1] = org.y; o.pos[2] = org.z;
                 o.nrm[0] = refl.x; o.nrm[1] = refl.y; o.nrm[2] = refl.z;
                 o.sample = sample;
                 o.pad[0] = nl; o.pad[1] = o.pad[2] = 0;
-                qout[atomicAdd(qout_count, 1u)] = o;                   // the compiler aggregates this per wavefront
+                append = true;
             }
+        }
+        }
+        const unsigned long long am = __ballot(append);
+        if (lane == 0u) s_cnt[parity][wave] = (unsigned int)__popcll(am);
+        __syncthreads();
+        if (threadIdx.x == 0u) {
+            const unsigned int n = s_cnt[parity][0] + s_cnt[parity][1] + s_cnt[parity][2] + s_cnt[parity][3];
+            s_base[parity] = n ? atomicAdd(qout_count, n) : 0u;
+        }
+        __syncthreads();
+        if (append) {
+            unsigned int at = s_base[parity] + (unsigned int)__popcll(am & lanemask_lt());
+            for (unsigned int w = 0; w < wave; ++w) at += s_cnt[parity][w];
+            qout[at] = o;
         }
     }
     if (STATS && EXTRA) {
