@@ -59,7 +59,9 @@ static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 // n == 0: inner node index c (into the Bvh4Node array); n < 0: empty slot.  The children of the stored tree are in build order;
 // the walks read per-frame COPIES whose children are sorted front to back for the frame's ray origin / back to front for its
 // light (k_order_nodes): rays with a common origin (or a common end) meet the subtrees of a node in the same order whatever
-// their direction, so a packet walk needs no per-step vote -- slot 0 first, the others pushed far to near.
+// their direction, so a packet walk needs no per-step vote -- slot 0 first, the others pushed far to near.  The LIGHT-ordered copy also
+// re-arranges a child's six planes (slots lo[0..2], hi[0..2] hold lo.x, lo.y, hi.x, hi.y, lo.z, hi.z) and, on the axes where the light lies outside
+// the root box, stores (near, far) instead of (lo, hi): only k_shaft_pkt4 reads it (shaft_slabs).
 struct alignas(16) Bvh4Child {
     float   lo[3], hi[3];
     int32_t c, n;
